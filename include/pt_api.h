@@ -1,0 +1,225 @@
+/*
+ * pt_api.h - C ABI of libptcore, the MI355X render core.
+ *
+ * The reference application has no callable render API: a render is started, polled and aborted
+ * by three code blocks inside its frame function that operate on fields of one big AppData
+ * struct.  Every entry point below names the reference block it replaces.  All structs are plain
+ * data (no pointers owned by the caller survive a call, the library deep-copies its inputs), all
+ * entry points return 0 on success or a negative PT_ERR_* code and never exit or throw.
+ */
+#ifndef PT_API_H
+#define PT_API_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Geometry types, numbered as the reference's GEOM_TYPE_* enum (code/raycast.cpp:5-13). */
+enum {
+	PT_GEOM_SPHERE = 0,   /* ellipsoid; a true sphere when the three dims are equal */
+	PT_GEOM_BOX = 1,
+	PT_GEOM_CYLINDER = 2,
+	PT_GEOM_CONE = 3,
+	PT_GEOM_PLANE = 4,    /* accepted by the CPU oracle only; the device path rejects it */
+};
+
+enum {
+	PT_OK = 0,
+	PT_ERR_ARG = -1,       /* invalid argument / unsupported value */
+	PT_ERR_DEVICE = -2,    /* HIP runtime error, see pt_last_error */
+	PT_ERR_BUSY = -3,      /* a render is already active on this context */
+	PT_ERR_STATE = -4,     /* call made in the wrong state (e.g. trace before prepare) */
+	PT_ERR_NOMEM = -5,
+	PT_ERR_LIMIT = -6,     /* size beyond a documented maximum */
+};
+
+/* Seed policies.  The reference reseeds from the cycle counter per tile job and so defines no
+ * reproducible sequence (code/raycast.cpp:994); these are the two deterministic replacements. */
+enum {
+	PT_SEED_PER_JOB = 1,    /* one PCG stream per tile job, pixels and samples consumed serially
+	                           inside the job - the reference's structure; CPU oracle only */
+	PT_SEED_PER_SAMPLE = 3, /* one PCG stream per pixel (lens table start) and one per camera
+	                           sample (all bounce draws); device path and CPU oracle */
+};
+
+/* Authoring fields of one entity: Object / Material / Geometry of code/raycast.cpp:23-78 without
+ * the precalculated members, which the library derives itself (code/raycast.cpp:2064-2108). */
+typedef struct pt_object {
+	float pos[3];
+	float rot[4];            /* quaternion, order w,x,y,z (code/rt_math.cpp:2789-2801) */
+	float dim[3];            /* sphere: diameters; box: edge lengths; cylinder/cone: x,y diameters, z height */
+	float color[3];          /* gamma-2.2 space */
+	int32_t type;            /* PT_GEOM_* */
+	float emit_color[3];     /* gamma-2.2 space */
+	float reflection_mod;    /* 0 diffuse .. 1 mirror */
+	float refractive_index;  /* 1 = opaque */
+	float roughness;         /* Oren-Nayar, 0 = off */
+} pt_object;
+
+/* Camera of code/raycast.cpp:148-156; image-plane height, plane distance and the orientation
+ * vectors are derived (code/app.cpp:1077-1090). */
+typedef struct pt_camera {
+	float pos[3];
+	float rot[3];            /* x = yaw about +Z, y = pitch, z unused by the reference */
+	float fov;               /* degrees */
+	float plane_width;       /* Camera::dim.w, image-plane width in world units */
+} pt_camera;
+
+/* World of code/raycast.cpp:245-269 without the object array and the derived members. */
+typedef struct pt_world {
+	pt_camera camera;
+	float background_color[3];   /* gamma space */
+	float ambient_color[3];
+	float light_color[3];
+	int32_t light_rot[2];        /* degrees, World::globalLightRot */
+	float focal_distance;
+	float aperture;              /* 0 = pinhole */
+} pt_world;
+
+/* RaytraceSettings of code/raycast.cpp:320-358 (authoring members) plus the constants the
+ * reference hard-codes, with the reference value noted. */
+typedef struct pt_settings {
+	int32_t width, height;       /* texDim; reference UI clamps to 256..10000 */
+	int32_t spp_wanted;          /* sampleCountWanted (code/app.cpp:641) */
+	int32_t sample_grid_width;   /* blue-noise tile width in pixels, 3 (code/app.cpp:642) */
+	int32_t max_bounces;         /* rayBouncesMaxWanted */
+	int32_t grid_hint;           /* cells per axis asked of spatialGridInit, 10 (code/app.cpp:1276) */
+	int32_t brute_force_below;   /* object count under which every object is tested, 10 (code/raycast.cpp:1100) */
+	int32_t seed_policy;         /* PT_SEED_* */
+	uint64_t seed;               /* tables + blue noise are drawn from PCG stream (0, seed);
+	                                path streams use it as their initstate */
+	int32_t part_index;          /* this context renders the image tiles t with t % part_count == part_index */
+	int32_t part_count;          /* 1 = whole image */
+	int32_t frame_index;         /* progressive mode: >= 0 traces ONE sample per pixel, sample
+	                                (frame_index mod count(tile)), and adds it into the accumulation
+	                                buffer; -1 = full render of every sample */
+	int32_t reserved;
+} pt_settings;
+
+typedef struct pt_progress {
+	int32_t done;                /* 1 once the frame is complete (or aborted) */
+	int32_t aborted;
+	float fraction;              /* 0..1, share of bounce passes finished */
+	double seconds;              /* since pt_render_start, the reference's processTime (code/app.cpp:1440) */
+	uint64_t paths_done;
+} pt_progress;
+
+typedef struct pt_stats {
+	uint64_t paths;              /* camera samples in this context's partition (exact) */
+	uint64_t rays;               /* ray casts issued on the device */
+	uint64_t pixels;             /* pixels in this context's partition */
+	uint64_t zero_sample_pixels; /* pixels whose blue-noise tile drew no sample (written as 0) */
+	int32_t samples_total;       /* entries in the blue-noise sample table */
+	int32_t objects;
+	int32_t cells[3];
+	int32_t cell_size[3];
+	int32_t cell_items;          /* entries in the CSR item array */
+	int32_t bounce_passes;       /* extend/shade launches of the last trace */
+	float trace_ms;              /* device time of the last trace (HIP events) */
+	float dominant_kernel_ms;    /* summed device time of the extend/shade kernel in the last trace */
+	float prepare_ms;            /* host flatten + grid + tables + upload */
+} pt_stats;
+
+typedef struct pt_ctx pt_ctx;
+
+/* Library lifetime.  `device` is a HIP device ordinal. */
+pt_ctx* pt_create(int device);
+void pt_destroy(pt_ctx* ctx);
+const char* pt_last_error(const pt_ctx* ctx);   /* ctx may be NULL: error of a failed pt_create */
+void pt_default_settings(pt_settings* s);
+
+/* The demo scene of code/raycast.cpp:1294-1356 (ground box + mirror sphere). objects must hold 2. */
+int pt_default_scene(pt_world* world, pt_object* objects, int capacity, int* count);
+
+/*
+ * Replaces the render-start block code/app.cpp:1140-1423: validates, deep-copies the inputs,
+ * runs per-object precalc, builds sample tables and the uniform grid, uploads, launches the
+ * tracer on a worker thread and returns immediately.  `rgb` (width*height*3 floats, linear,
+ * clamped to [0,1], row 0 = top) is caller-owned and filled on completion, like AppData::buffer
+ * (code/app.cpp:1156-1159, code/raycast.cpp:1270).
+ */
+int pt_render_start(pt_ctx* ctx, const pt_world* world, const pt_object* objects, int n_objects,
+                    const pt_settings* settings, float* rgb);
+
+/* Replaces the per-frame poll code/app.cpp:1436-1440 (threadQueueFinished + processTime). */
+int pt_render_progress(pt_ctx* ctx, pt_progress* info);
+
+/* Replaces the Escape handler code/app.cpp:1425-1428: the flag is honoured between bounce passes;
+ * the buffer content after an abort is partial, as in the reference. */
+int pt_render_abort(pt_ctx* ctx);
+
+/* Blocks until the active render is done (headless harness). Returns the render's status. */
+int pt_render_wait(pt_ctx* ctx);
+
+/*
+ * The same work split in three, for callers that keep the scene resident (benchmarks,
+ * progressive display, torch interop):
+ *   pt_prepare  - host flatten + tables + grid + upload  (code/app.cpp:1161-1357)
+ *   pt_trace    - all device passes into a device framebuffer (code/raycast.cpp:991-1289)
+ *   pt_download - device framebuffer -> host
+ * d_rgb may be NULL (library-owned framebuffer) or a device pointer to width*height*3 floats;
+ * hip_stream may be NULL (library stream) or a hipStream_t.  pt_trace is synchronous with
+ * respect to the host only when `sync` is non-zero.
+ */
+int pt_prepare(pt_ctx* ctx, const pt_world* world, const pt_object* objects, int n_objects,
+               const pt_settings* settings);
+int pt_trace(pt_ctx* ctx, float* d_rgb, void* hip_stream, int sync);
+int pt_set_frame(pt_ctx* ctx, int frame_index);          /* progressive mode frame counter */
+int pt_download(pt_ctx* ctx, float* rgb);
+int pt_get_stats(const pt_ctx* ctx, pt_stats* stats);
+
+/*
+ * Debug outputs the parity contract needs and the reference lacks: for camera sample 0 of every
+ * pixel, the 1-based id of the entity the primary ray hits (0 = miss) and a hash of the grid
+ * cells the ray visited (0 when the brute-force path was taken).  Runs its own small pass over
+ * the prepared scene.
+ */
+int pt_debug_primary(pt_ctx* ctx, int32_t* hit_id, uint64_t* cell_hash);
+
+/* One-ray query through the prepared scene: the editor's picking ray (code/app.cpp:1634-1637)
+ * and focal-distance picker (code/app.cpp:3233-3247). Returns the 1-based id or 0. */
+int pt_cast_rays(pt_ctx* ctx, const float* origins, const float* dirs, int n,
+                 int32_t* hit_id, float* hit_pos, float* hit_normal);
+
+/* Screenshot stage code/app.cpp:1536-1552: linear float -> sRGB OETF -> 8-bit, on the device
+ * framebuffer of the last trace. rgb8 holds width*height*3 bytes. */
+int pt_present_srgb8(pt_ctx* ctx, uint8_t* rgb8);
+
+/* ---- host stages, exported so they can be checked without a GPU -------------------------- */
+
+/* Flattened per-object record: the members of Object the tracer reads, after
+ * preCalcObjects (code/raycast.cpp:2064-2108). 36 floats per object in the order below. */
+enum {
+	PT_F_POS = 0, PT_F_ROT = 3, PT_F_ROTINV = 7, PT_F_DIM = 11, PT_F_SCALE = 14, PT_F_SCALEINV = 17,
+	PT_F_COLOR = 20, PT_F_EMIT = 23, PT_F_BBOX = 26, PT_F_BRADIUS = 29, PT_F_REFL = 30, PT_F_IOR = 31,
+	PT_F_ROUGH = 32, PT_F_TYPE = 33 /* int bits */, PT_F_FLAGS = 34 /* bit0 isRotated, bit1 evenDim */,
+	PT_F_PAD = 35, PT_F_STRIDE = 36,
+};
+int pt_host_flatten(const pt_object* objects, int n, float* records /* n*PT_F_STRIDE */);
+
+/* Derived camera/world constants: 27 floats:
+ * dim_h, near_dist, dir[3], up[3], right[3], top_left[3], light_dir[3], bg[3], ambient[3], light[3], pad */
+enum { PT_W_DIMH = 0, PT_W_NEAR = 1, PT_W_DIR = 2, PT_W_UP = 5, PT_W_RIGHT = 8, PT_W_TOPLEFT = 11,
+       PT_W_LIGHTDIR = 14, PT_W_BG = 17, PT_W_AMBIENT = 20, PT_W_LIGHT = 23, PT_W_COUNT = 27 };
+int pt_host_world(const pt_world* world, int width, int height, float* out /* PT_W_COUNT */);
+
+/* Random tables of code/app.cpp:669-727 followed by the blue-noise sample table of
+ * code/app.cpp:1161-1225, all drawn from PCG stream (0, seed) in that order.
+ * dirs: 20000*3, disc: 20000*2, samples: capacity*2, offsets: grid_width^2+1. */
+enum { PT_TABLE_COUNT = 20000 };
+int pt_host_tables(uint64_t seed, int spp_wanted, int grid_width, float* dirs, float* disc,
+                   float* samples, int sample_capacity, int32_t* offsets, int* sample_count);
+
+/* Uniform grid of code/raycast.cpp:595-617 + code/app.cpp:1247-1357 in CSR form, with the
+ * intended append semantics (ascending object id per cell).  grid_ints: coordMin[3], cellCount[3],
+ * cellSize[3].  Call with cell_start == NULL to size the arrays first. */
+int pt_host_grid(const float* records, int n, int hint, int32_t* grid_ints /* 9 */,
+                 uint32_t* cell_start, int cell_capacity, uint32_t* cell_items, int item_capacity,
+                 int* cell_total, int* item_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_API_H */

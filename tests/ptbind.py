@@ -1,0 +1,202 @@
+"""ctypes bindings shared by the tests, bench.py and __graft_entry__.py.
+
+Three libraries are bound here:
+  libptcore.so   (pathtracer_amd/)   - the product: C ABI of include/pt_api.h, HIP kernels inside
+  libptoracle.so (oracle/)           - the CPU restatement, test infrastructure only
+  libptref.so    (oracle/_ref/)      - the reference's own code compiled as a library (optional)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+PT_GEOM_SPHERE, PT_GEOM_BOX, PT_GEOM_CYLINDER, PT_GEOM_CONE, PT_GEOM_PLANE = range(5)
+PT_SEED_PER_JOB, PT_SEED_PER_SAMPLE = 1, 3
+PT_F_STRIDE = 36
+PT_W_COUNT = 27
+PT_TABLE_COUNT = 20000
+F = dict(POS=0, ROT=3, ROTINV=7, DIM=11, SCALE=14, SCALEINV=17, COLOR=20, EMIT=23, BBOX=26,
+         BRADIUS=29, REFL=30, IOR=31, ROUGH=32, TYPE=33, FLAGS=34)
+
+
+class pt_object(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("rot", C.c_float * 4), ("dim", C.c_float * 3),
+                ("color", C.c_float * 3), ("type", C.c_int32), ("emit_color", C.c_float * 3),
+                ("reflection_mod", C.c_float), ("refractive_index", C.c_float),
+                ("roughness", C.c_float)]
+
+
+class pt_camera(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("rot", C.c_float * 3), ("fov", C.c_float),
+                ("plane_width", C.c_float)]
+
+
+class pt_world(C.Structure):
+    _fields_ = [("camera", pt_camera), ("background_color", C.c_float * 3),
+                ("ambient_color", C.c_float * 3), ("light_color", C.c_float * 3),
+                ("light_rot", C.c_int32 * 2), ("focal_distance", C.c_float),
+                ("aperture", C.c_float)]
+
+
+class pt_settings(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp_wanted", C.c_int32),
+                ("sample_grid_width", C.c_int32), ("max_bounces", C.c_int32),
+                ("grid_hint", C.c_int32), ("brute_force_below", C.c_int32),
+                ("seed_policy", C.c_int32), ("seed", C.c_uint64), ("part_index", C.c_int32),
+                ("part_count", C.c_int32), ("frame_index", C.c_int32), ("reserved", C.c_int32)]
+
+
+class pt_progress(C.Structure):
+    _fields_ = [("done", C.c_int32), ("aborted", C.c_int32), ("fraction", C.c_float),
+                ("seconds", C.c_double), ("paths_done", C.c_uint64)]
+
+
+class pt_stats(C.Structure):
+    _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("pixels", C.c_uint64),
+                ("zero_sample_pixels", C.c_uint64), ("samples_total", C.c_int32),
+                ("objects", C.c_int32), ("cells", C.c_int32 * 3), ("cell_size", C.c_int32 * 3),
+                ("cell_items", C.c_int32), ("bounce_passes", C.c_int32), ("trace_ms", C.c_float),
+                ("dominant_kernel_ms", C.c_float), ("prepare_ms", C.c_float)]
+
+
+def default_settings(width=64, height=36, spp=16, bounces=8, seed=12345, **kw):
+    s = pt_settings()
+    s.width, s.height, s.spp_wanted = width, height, spp
+    s.sample_grid_width, s.max_bounces, s.grid_hint = 3, bounces, 10
+    s.brute_force_below, s.seed_policy, s.seed = 10, PT_SEED_PER_SAMPLE, seed
+    s.part_index, s.part_count, s.frame_index = 0, 1, -1
+    for k, v in kw.items():
+        setattr(s, k, v)
+    return s
+
+
+def make_object(pos, dim, type=PT_GEOM_SPHERE, rot=(1, 0, 0, 0), color=(0.5, 0.5, 0.5),
+                emit=(0, 0, 0), refl=0.0, ior=1.0, rough=0.0):
+    o = pt_object()
+    o.pos[:] = pos
+    o.rot[:] = rot
+    o.dim[:] = dim
+    o.color[:] = color
+    o.type = type
+    o.emit_color[:] = emit
+    o.reflection_mod, o.refractive_index, o.roughness = refl, ior, rough
+    return o
+
+
+def make_world(cam_pos=(0, -30, 7), cam_rot=(0, 0, 0), fov=90.0, plane_width=10.0,
+               bg=(1, 1, 1), ambient=(1, 1, 1), light=(1, 1, 1), light_rot=(0, 90),
+               focal_distance=30.0, aperture=0.0):
+    w = pt_world()
+    w.camera.pos[:] = cam_pos
+    w.camera.rot[:] = cam_rot
+    w.camera.fov, w.camera.plane_width = fov, plane_width
+    w.background_color[:] = bg
+    w.ambient_color[:] = ambient
+    w.light_color[:] = light
+    w.light_rot[:] = light_rot
+    w.focal_distance, w.aperture = focal_distance, aperture
+    return w
+
+
+def object_array(objs):
+    arr = (pt_object * max(1, len(objs)))()
+    for i, o in enumerate(objs):
+        arr[i] = o
+    return arr
+
+
+def fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def iptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def uptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def u64ptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def u8ptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+REF_PATH = os.path.join(ROOT, "oracle", "_ref", "libptref.so")
+ORACLE_PATH = os.path.join(ROOT, "oracle", "libptoracle.so")
+CORE_PATH = os.path.join(ROOT, "pathtracer_amd", "libptcore.so")
+
+_libs = {}
+
+
+def _load(path):
+    if path not in _libs:
+        _libs[path] = C.CDLL(path)
+    return _libs[path]
+
+
+def have_ref():
+    return os.path.exists(REF_PATH)
+
+
+def load_ref():
+    lib = _load(REF_PATH)
+    lib.ref_pcg_seed.argtypes = [C.c_uint64, C.c_uint64]
+    lib.ref_render.argtypes = [C.c_uint64, C.POINTER(C.c_float)]
+    lib.ref_render_rect.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    return lib
+
+
+def load_oracle():
+    lib = _load(ORACLE_PATH)
+    lib.pto_pcg_seed.argtypes = [C.c_uint64, C.c_uint64]
+    lib.pto_render.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_float)]
+    lib.pto_scene_create.restype = C.c_void_p
+    for name in ("pto_scene_destroy", "pto_get_samples", "pto_get_records", "pto_get_world",
+                 "pto_get_grid", "pto_get_cell", "pto_get_intersection", "pto_traverse",
+                 "pto_cast", "pto_jobs", "pto_primary", "pto_render_mt", "pto_get_tables",
+                 "pto_sample_radiance", "pto_counters", "pto_path_count", "pto_cell_hashes"):
+        if hasattr(lib, name):
+            getattr(lib, name).argtypes = None
+    return lib
+
+
+def load_core():
+    if not os.path.exists(CORE_PATH):
+        raise RuntimeError("libptcore.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = _load(CORE_PATH)
+    lib.pt_create.restype = C.c_void_p
+    lib.pt_create.argtypes = [C.c_int]
+    lib.pt_destroy.argtypes = [C.c_void_p]
+    lib.pt_last_error.restype = C.c_char_p
+    lib.pt_last_error.argtypes = [C.c_void_p]
+    lib.pt_render_start.argtypes = [C.c_void_p, C.POINTER(pt_world), C.POINTER(pt_object), C.c_int,
+                                    C.POINTER(pt_settings), C.POINTER(C.c_float)]
+    lib.pt_render_progress.argtypes = [C.c_void_p, C.POINTER(pt_progress)]
+    lib.pt_render_abort.argtypes = [C.c_void_p]
+    lib.pt_render_wait.argtypes = [C.c_void_p]
+    lib.pt_prepare.argtypes = [C.c_void_p, C.POINTER(pt_world), C.POINTER(pt_object), C.c_int,
+                               C.POINTER(pt_settings)]
+    lib.pt_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.pt_set_frame.argtypes = [C.c_void_p, C.c_int]
+    lib.pt_download.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.pt_get_stats.argtypes = [C.c_void_p, C.POINTER(pt_stats)]
+    lib.pt_debug_primary.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+    lib.pt_cast_rays.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
+                                 C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.pt_present_srgb8.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
+    lib.pt_default_scene.argtypes = [C.POINTER(pt_world), C.POINTER(pt_object), C.c_int, C.POINTER(C.c_int)]
+    lib.pt_default_settings.argtypes = [C.POINTER(pt_settings)]
+    lib.pt_host_flatten.argtypes = [C.POINTER(pt_object), C.c_int, C.POINTER(C.c_float)]
+    lib.pt_host_world.argtypes = [C.POINTER(pt_world), C.c_int, C.c_int, C.POINTER(C.c_float)]
+    lib.pt_host_tables.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                   C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int)]
+    lib.pt_host_grid.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_int32),
+                                 C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32), C.c_int,
+                                 C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    return lib
