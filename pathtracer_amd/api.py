@@ -1,9 +1,7 @@
-"""ctypes bindings shared by the tests, bench.py and __graft_entry__.py.
+"""ctypes mirror of include/pt_api.h and the loader of libptcore.so (the HIP render core).
 
-Three libraries are bound here:
-  libptcore.so   (pathtracer_amd/)   - the product: C ABI of include/pt_api.h, HIP kernels inside
-  libptoracle.so (oracle/)           - the CPU restatement, test infrastructure only
-  libptref.so    (oracle/_ref/)      - the reference's own code compiled as a library (optional)
+Nothing here computes: every call goes through the C ABI.  There is no CPU fallback - if the
+library is missing or the device fails, the call raises.
 """
 import ctypes as C
 import os
@@ -11,6 +9,14 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CORE_PATH = os.path.join(ROOT, "pathtracer_amd", "libptcore.so")
+_libs = {}
+
+
+def _load(path):
+    if path not in _libs:
+        _libs[path] = C.CDLL(path)
+    return _libs[path]
 
 PT_GEOM_SPHERE, PT_GEOM_BOX, PT_GEOM_CYLINDER, PT_GEOM_CONE, PT_GEOM_PLANE = range(5)
 PT_SEED_PER_JOB, PT_SEED_PER_SAMPLE = 1, 3
@@ -125,45 +131,6 @@ def u64ptr(a):
 
 def u8ptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint8))
-
-
-REF_PATH = os.path.join(ROOT, "oracle", "_ref", "libptref.so")
-ORACLE_PATH = os.path.join(ROOT, "oracle", "libptoracle.so")
-CORE_PATH = os.path.join(ROOT, "pathtracer_amd", "libptcore.so")
-
-_libs = {}
-
-
-def _load(path):
-    if path not in _libs:
-        _libs[path] = C.CDLL(path)
-    return _libs[path]
-
-
-def have_ref():
-    return os.path.exists(REF_PATH)
-
-
-def load_ref():
-    lib = _load(REF_PATH)
-    lib.ref_pcg_seed.argtypes = [C.c_uint64, C.c_uint64]
-    lib.ref_render.argtypes = [C.c_uint64, C.POINTER(C.c_float)]
-    lib.ref_render_rect.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
-    return lib
-
-
-def load_oracle():
-    lib = _load(ORACLE_PATH)
-    lib.pto_pcg_seed.argtypes = [C.c_uint64, C.c_uint64]
-    lib.pto_render.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_float)]
-    lib.pto_scene_create.restype = C.c_void_p
-    for name in ("pto_scene_destroy", "pto_get_samples", "pto_get_records", "pto_get_world",
-                 "pto_get_grid", "pto_get_cell", "pto_get_intersection", "pto_traverse",
-                 "pto_cast", "pto_jobs", "pto_primary", "pto_render_mt", "pto_get_tables",
-                 "pto_sample_radiance", "pto_counters", "pto_path_count", "pto_cell_hashes"):
-        if hasattr(lib, name):
-            getattr(lib, name).argtypes = None
-    return lib
 
 
 def load_core():
