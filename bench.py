@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Benchmark of the render core: Mpaths/s on the 1080p / 64 spp / depth 8 demo scene.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one whole frame: every pixel of the image traced to completion on the GPU(s), scene
+and tables already resident in HBM.  With N > 1 (launched by torch.distributed.run, one rank per
+GPU) the frame's 8x8 tiles are dealt round-robin to the ranks, each rank traces its share, and the
+tile buffers are gathered on rank 0 over RCCL and laid out as the image there - the one inter-GPU
+step of the path.  The frame is fixed as N grows (strong scaling).
+
+Rank 0 prints one JSON line.  Besides the contract fields it carries
+  roofline      fp32 VALU roofline of the dominant kernel (pt_k_trace): algorithmic flops per frame
+                (event counts of the CPU oracle on the same workload x per-event weights) over the
+                kernel's duration measured with HIP events on the launch stream;
+  cpu_baseline  the CPU renderer timed on this host's cores on the same frame, scheduled like the
+                reference (tile jobs, cores-1 workers).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from pathtracer_amd import api, scenes  # noqa: E402
+
+# fp32 operations per event, from the reference source (one add, mul, divide, sqrt or compare each).
+FLOP_WEIGHTS = {
+    "casts": 70,            # grid entry / traverse init (code/raycast.cpp:619-670)
+    "dda_steps": 6,         # spatialGridTraverseNext
+    "bsphere_tests": 20,    # lineSphereCollision
+    "isect_sphere": 35, "isect_box": 40, "isect_cylinder": 45, "isect_cone": 50,
+    "unit_space": 170,      # transformToUnitSpace + transformToGlobalSpace + distance (code/raycast.cpp:750-770)
+    "rotated_box": 75,
+    "shade_opaque": 40, "shade_oren": 60, "shade_glass": 65,
+    "paths": 25 + 6,        # camera ray + accumulate
+    "lens": 40,
+}
+PEAK_FP32_VALU_TFLOPS = 157.3      # MI355X vector fp32 peak (packed FMA); plain add/mul code can reach half of it
+
+
+def flops_from_counters(c):
+    unit = c["uneven_sphere"] + c["isect_cylinder"] + c["isect_cone"]
+    total = 0
+    for k, w in FLOP_WEIGHTS.items():
+        if k == "unit_space":
+            total += unit * w
+        else:
+            total += c[k] * w
+    return total
+
+
+def workload(name):
+    if name == "demo-1080p-64spp-d8":
+        world, objs = scenes.default_scene()
+        return world, objs, dict(width=1920, height=1080, spp=64, bounces=8, seed=12345)
+    if name == "demo-640x360-16spp-d8":
+        world, objs = scenes.default_scene()
+        return world, objs, dict(width=640, height=360, spp=16, bounces=8, seed=12345)
+    if name == "glass-1080p-128spp-d32":
+        world, objs = scenes.glass_scene(seed=3, per_type=16)
+        return world, objs, dict(width=1920, height=1080, spp=128, bounces=32, seed=12345)
+    if name == "dense100k-4k-256spp-d8":
+        world, objs = scenes.dense_scene(n=100000, seed=4)
+        return world, objs, dict(width=3840, height=2160, spp=256, bounces=8, seed=12345, grid_hint=64)
+    raise SystemExit(f"unknown workload {name}")
+
+
+def cpu_baseline(world, objs, kw, budget_paths=160e6):
+    """CPU renderer on this host: the reference's own code where oracle/_ref was built, else the
+    oracle port; tile jobs in the reference's order on cores-1 worker threads."""
+    from oracle import oraclebind
+    from oracle.oraclebind import FP, OracleScene
+    cores = max(1, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "1024"))) - 1)
+    kw = dict(kw)
+    st = api.default_settings(kw.pop("width"), kw.pop("height"), kw.pop("spp"), kw.pop("bounces"), **kw)
+    sc = OracleScene(world, objs, st)
+    paths = sc.path_count()
+    sample = f"whole frame {st.width}x{st.height}"
+    if paths > budget_paths:          # keep the leg to tens of seconds: a centred crop of the same frame
+        scale = (budget_paths / paths) ** 0.5
+        st.width, st.height = max(64, int(st.width * scale) // 16 * 16), max(36, int(st.height * scale) // 9 * 9)
+        sc.close()
+        sc = OracleScene(world, objs, st)
+        paths = sc.path_count()
+        sample = f"same scene and spp at {st.width}x{st.height}"
+    img = np.zeros((st.height, st.width, 3), np.float32)
+    t0 = time.perf_counter()
+    sc.lib.pto_render_mt(sc.h, st.seed, api.PT_SEED_PER_JOB, cores, img.ctypes.data_as(FP))
+    dt = time.perf_counter() - t0
+    counters = sc.counters()
+    out = {"value": paths / dt / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
+           "sample": f"{sample}, {paths} paths, {dt:.2f} s"}
+    if oraclebind.have_ref() and len(objs) < 10000:
+        ref = oraclebind.load_ref()
+        if hasattr(ref, "ref_render_mt"):
+            ref.ref_pcg_seed(0, st.seed)
+            ref.ref_tables(None, None)
+            oa = api.object_array(objs)
+            ref.ref_scene_setup(C.byref(world), oa, len(objs), C.byref(st), 1)
+            t0 = time.perf_counter()
+            ref.ref_render_mt(st.seed, cores, img.ctypes.data_as(FP))
+            dt = time.perf_counter() - t0
+            out.update({"value": paths / dt / 1e6, "kind": "reference", "sample": f"{sample}, {paths} paths, {dt:.2f} s"})
+    sc.close()
+    return out, counters, paths
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="demo-1080p-64spp-d8")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    if world_size > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    world, objs, kw = workload(args.workload)
+    skw = dict(kw)
+    st = api.default_settings(skw.pop("width"), skw.pop("height"), skw.pop("spp"), skw.pop("bounces"),
+                              part_index=rank, part_count=world_size, **skw)
+    r = api.Renderer(local_rank)
+    r.prepare(world, objs, st)
+    stats = r.stats()
+    part_floats = r.partition_floats()
+
+    stream = torch.cuda.current_stream()
+    if world_size > 1:
+        # tile-major partition buffers; rank 0 gathers them and assembles the image
+        floats_max = torch.tensor([part_floats], device="cuda")
+        dist.all_reduce(floats_max, op=dist.ReduceOp.MAX)
+        stride = int(floats_max.item())
+        mine = torch.zeros(stride, dtype=torch.float32, device="cuda")
+        gathered = torch.empty(world_size * stride, dtype=torch.float32, device="cuda") if rank == 0 else None
+        image = torch.empty(st.height * st.width * 3, dtype=torch.float32, device="cuda") if rank == 0 else None
+    else:
+        image = torch.empty(st.height * st.width * 3, dtype=torch.float32, device="cuda")
+
+    def step():
+        if world_size == 1:
+            r.trace(d_rgb=image.data_ptr(), stream=stream.cuda_stream, sync=False)
+        else:
+            r.trace(d_rgb=mine.data_ptr(), stream=stream.cuda_stream, sync=False)
+            if rank == 0:
+                dist.gather(mine, [gathered[i * stride:(i + 1) * stride] for i in range(world_size)], dst=0)
+                r.assemble(gathered.data_ptr(), stride, world_size, st.width, st.height, image.data_ptr(), stream.cuda_stream)
+            else:
+                dist.gather(mine, None, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    r.sync()
+    if world_size > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world_size > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    r.sync()                                   # folds the HIP events of the K launches into the statistics
+    kstats = r.stats()
+
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    p = torch.tensor([float(stats.paths)], dtype=torch.float64, device="cuda")
+    k = torch.tensor([float(kstats.trace_ms)], dtype=torch.float64, device="cuda")
+    if world_size > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(p, op=dist.ReduceOp.SUM)
+        dist.all_reduce(k, op=dist.ReduceOp.MAX)
+    dt, total_paths, kernel_ms = float(t.item()), float(p.item()), float(k.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        out = {
+            "metric": "Mpaths/s, 1080p 64spp demo scene" if args.workload == "demo-1080p-64spp-d8" else f"Mpaths/s, {args.workload}",
+            "value": total_paths * args.steps / dt / 1e6, "unit": "Mpaths/s",
+            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "seconds_per_frame": ms_per_step / 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "width": st.width, "height": st.height, "spp_wanted": st.spp_wanted,
+                       "max_bounces": st.max_bounces, "objects": len(objs), "paths_per_frame": int(total_paths),
+                       "rays_per_frame_rank0": int(kstats.rays), "partition": f"8x8 tiles round-robin over {world_size} GPU(s)",
+                       "seed_policy": "per-sample PCG32 streams"},
+        }
+        roof = {"bound": "valu", "kernel": "pt_k_trace", "achieved": None, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                "frac": None, "traffic": None, "kernel_ms": kernel_ms}
+        if not args.no_cpu:
+            base, counters, base_paths = cpu_baseline(world, objs, kw)
+            out["cpu_baseline"] = base
+            flops_per_path = flops_from_counters(counters) / max(1, counters["paths"])
+            flops_per_launch = flops_per_path * total_paths / world_size
+            roof["flops_per_path"] = flops_per_path
+            roof["achieved"] = flops_per_launch / (kernel_ms * 1e-3) / 1e12
+            roof["frac"] = roof["achieved"] / PEAK_FP32_VALU_TFLOPS
+            roof["frac_of_no_fma_peak"] = roof["achieved"] / (PEAK_FP32_VALU_TFLOPS / 2)
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                m = json.load(open(pmc))
+                if m.get("workload") == args.workload and m.get("n_gpus", 1) == world_size:
+                    roof["traffic"] = m.get("hbm_bytes_per_launch")
+                    roof["traffic_source"] = m.get("source")
+            except Exception:
+                pass
+        out["roofline"] = roof
+        # algorithmic HBM bytes of the frame: the fp32 framebuffer (12 B per pixel), written once
+        out["hbm_algorithmic_bytes_per_launch"] = int(12 * stats.pixels)
+        print(json.dumps(out), flush=True)
+    r.close()
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -10,6 +10,7 @@
 #ifndef PT_API_H
 #define PT_API_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -166,6 +167,7 @@ int pt_render_wait(pt_ctx* ctx);
 int pt_prepare(pt_ctx* ctx, const pt_world* world, const pt_object* objects, int n_objects,
                const pt_settings* settings);
 int pt_trace(pt_ctx* ctx, float* d_rgb, void* hip_stream, int sync);
+int pt_sync(pt_ctx* ctx);                                /* waits for queued pt_trace calls, updates the statistics */
 int pt_set_frame(pt_ctx* ctx, int frame_index);          /* progressive mode frame counter */
 int pt_download(pt_ctx* ctx, float* rgb);
 int pt_get_stats(const pt_ctx* ctx, pt_stats* stats);
@@ -186,6 +188,18 @@ int pt_cast_rays(pt_ctx* ctx, const float* origins, const float* dirs, int n,
 /* Screenshot stage code/app.cpp:1536-1552: linear float -> sRGB OETF -> 8-bit, on the device
  * framebuffer of the last trace. rgb8 holds width*height*3 bytes. */
 int pt_present_srgb8(pt_ctx* ctx, uint8_t* rgb8);
+
+/*
+ * Multi-GPU: a context prepared with part_count > 1 renders the 8x8 image tiles t with
+ * t % part_count == part_index into a tile-major buffer of pt_partition_floats() floats
+ * ([local tile][64 pixels][3]).  After the partitions' buffers have been gathered on one device
+ * (the only inter-GPU step; the reference's counterpart is its workers writing one shared
+ * AppData::buffer, code/raycast.cpp:1270), pt_assemble lays them out as the row-major image.
+ * d_parts: part_count buffers, stride_floats apart; all pointers are device pointers.
+ */
+int pt_partition_floats(const pt_ctx* ctx, size_t* floats);
+int pt_assemble(pt_ctx* ctx, const float* d_parts, size_t stride_floats, int part_count, int width,
+                int height, float* d_rgb, void* hip_stream);
 
 /* ---- host stages, exported so they can be checked without a GPU -------------------------- */
 

@@ -62,6 +62,7 @@ def load_ref():
     _sig(lib, "ref_cast", None, C.c_int, FP, FP, C.c_int, IP, FP, FP)
     _sig(lib, "ref_jobs", C.c_int, IP)
     _sig(lib, "ref_render", C.c_int, C.c_uint64, FP)
+    _sig(lib, "ref_render_mt", C.c_int, C.c_uint64, C.c_int, FP)
     _sig(lib, "ref_render_rect", None, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, FP)
     _sig(lib, "ref_primary_hits", None, IP)
     _sig(lib, "ref_srgb8", None, C.c_int, FP, U8P)

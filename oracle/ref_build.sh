@@ -51,5 +51,5 @@ sed -n '351,353p;3634,3640p' "$C/rt_math.cpp" > /dev/null   # (present in math_p
 g++ -std=gnu++14 -O2 -fpermissive -w -ffp-contract=off -fPIC -shared \
 	'-D__declspec(x)=__thread' \
 	-I"$TMP" -I"$C" -I"$HERE/../include" \
-	"$HERE/ref_harness.cpp" -o "$OUT/libptref.so"
+	"$HERE/ref_harness.cpp" -o "$OUT/libptref.so" -lpthread
 echo "ref_build: built $OUT/libptref.so"

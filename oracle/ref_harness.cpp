@@ -17,6 +17,7 @@
 #include <float.h>
 #include <stdint.h>
 #include <inttypes.h>
+#include <pthread.h>
 #include <math.h>
 #include <limits>
 
@@ -25,7 +26,7 @@
 /* rt_types.cpp:8 typedefs `ushort` as unsigned char; glibc's sys/types.h already owns the name. */
 #define ushort ref_ushort
 
-static uint64_t g_ref_job_seed = 0;
+static __thread uint64_t g_ref_job_seed = 0;
 static inline uint64_t ref_rdtsc_hook() { return g_ref_job_seed; }
 #define __rdtsc() ref_rdtsc_hook()
 #define getCycleStamp() 0LL      /* only reached from the compiled-out timing macros */
@@ -337,6 +338,34 @@ int ref_render(uint64_t seed_base, float* rgb) {
 		ad->threadData[i].stopProcessing = false;
 		processPixelsThreaded(ad->threadData + i);
 	}
+	int pixelCount = ad->settings.texDim.w*ad->settings.texDim.h;
+	if(rgb) memcpy(rgb, ad->buffer, sizeof(Vec3)*pixelCount);
+	return jobs;
+}
+
+/* The same jobs handed out in order to `threads` workers - the reference's own scheduling
+ * (code/rt_misc_win32.cpp:45-74) with pthreads in place of the Win32 queue. */
+struct RefWorker { int jobs; volatile int* next; uint64_t seed_base; };
+static void* ref_worker_main(void* arg) {
+	RefWorker* w = (RefWorker*)arg;
+	for(;;) {
+		int i = __sync_fetch_and_add(w->next, 1);
+		if(i >= w->jobs) break;
+		g_ref_job_seed = w->seed_base + (uint64_t)i;
+		processPixelsThreaded(ad->threadData + i);
+	}
+	return 0;
+}
+int ref_render_mt(uint64_t seed_base, int threads, float* rgb) {
+	int jobs = ref_jobs(0);
+	if(threads < 1) threads = 1;
+	if(threads > 256) threads = 256;
+	for(int i = 0; i < jobs; i++) ad->threadData[i].stopProcessing = false;
+	volatile int next = 0;
+	RefWorker w = { jobs, &next, seed_base };
+	pthread_t tid[256];
+	for(int t = 0; t < threads; t++) pthread_create(&tid[t], 0, ref_worker_main, &w);
+	for(int t = 0; t < threads; t++) pthread_join(tid[t], 0);
 	int pixelCount = ad->settings.texDim.w*ad->settings.texDim.h;
 	if(rgb) memcpy(rgb, ad->buffer, sizeof(Vec3)*pixelCount);
 	return jobs;

@@ -166,4 +166,121 @@ def load_core():
     lib.pt_host_grid.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_int32),
                                  C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32), C.c_int,
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.pt_sync.argtypes = [C.c_void_p]
+    lib.pt_partition_floats.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    lib.pt_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     return lib
+
+
+class PtError(RuntimeError):
+    pass
+
+
+class Renderer:
+    """Thin host-side mirror of the C ABI: one context on one GPU.  Every method is a direct call
+    into libptcore.so; errors raise PtError with the library's message."""
+
+    def __init__(self, device=0):
+        self.lib = load_core()
+        self.ctx = self.lib.pt_create(device)
+        if not self.ctx:
+            raise PtError("pt_create failed: " + self.lib.pt_last_error(None).decode())
+        self.settings = None
+
+    def close(self):
+        if self.ctx:
+            self.lib.pt_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise PtError(f"{what} failed ({rc}): {self.lib.pt_last_error(self.ctx).decode()}")
+
+    # --- render start / progress / abort / wait (the reference's boundary) ---
+    def start(self, world, objs, settings, out=None):
+        self.settings = settings
+        self._objs = object_array(objs)
+        self._out = out if out is not None else np.zeros((settings.height, settings.width, 3), np.float32)
+        self._check(self.lib.pt_render_start(self.ctx, C.byref(world), self._objs, len(objs), C.byref(settings),
+                                             fptr(self._out)), "pt_render_start")
+        return self._out
+
+    def progress(self):
+        p = pt_progress()
+        rc = self.lib.pt_render_progress(self.ctx, C.byref(p))
+        self._check(rc, "pt_render_progress")
+        return p
+
+    def abort(self):
+        self._check(self.lib.pt_render_abort(self.ctx), "pt_render_abort")
+
+    def wait(self):
+        self._check(self.lib.pt_render_wait(self.ctx), "pt_render_wait")
+        return self._out
+
+    def render(self, world, objs, settings):
+        self.start(world, objs, settings)
+        return self.wait()
+
+    # --- resident-scene interface ---
+    def prepare(self, world, objs, settings):
+        self.settings = settings
+        self._objs = object_array(objs)
+        self._check(self.lib.pt_prepare(self.ctx, C.byref(world), self._objs, len(objs), C.byref(settings)), "pt_prepare")
+
+    def trace(self, d_rgb=None, stream=None, sync=True):
+        self._check(self.lib.pt_trace(self.ctx, d_rgb, stream, 1 if sync else 0), "pt_trace")
+
+    def sync(self):
+        self._check(self.lib.pt_sync(self.ctx), "pt_sync")
+
+    def set_frame(self, frame):
+        self._check(self.lib.pt_set_frame(self.ctx, frame), "pt_set_frame")
+
+    def download(self):
+        s = self.settings
+        out = np.zeros((s.height, s.width, 3), np.float32)
+        self._check(self.lib.pt_download(self.ctx, fptr(out)), "pt_download")
+        return out
+
+    def stats(self):
+        st = pt_stats()
+        self._check(self.lib.pt_get_stats(self.ctx, C.byref(st)), "pt_get_stats")
+        return st
+
+    def partition_floats(self):
+        n = C.c_size_t(0)
+        self._check(self.lib.pt_partition_floats(self.ctx, C.byref(n)), "pt_partition_floats")
+        return n.value
+
+    def assemble(self, d_parts, stride_floats, part_count, width, height, d_rgb, stream=None):
+        self._check(self.lib.pt_assemble(self.ctx, d_parts, stride_floats, part_count, width, height, d_rgb, stream), "pt_assemble")
+
+    def debug_primary(self):
+        s = self.settings
+        ids = np.zeros((s.height, s.width), np.int32)
+        hs = np.zeros((s.height, s.width), np.uint64)
+        self._check(self.lib.pt_debug_primary(self.ctx, iptr(ids), u64ptr(hs)), "pt_debug_primary")
+        return ids, hs
+
+    def cast_rays(self, origins, dirs):
+        o = np.ascontiguousarray(origins, np.float32)
+        d = np.ascontiguousarray(dirs, np.float32)
+        n = o.shape[0]
+        ids = np.zeros(n, np.int32)
+        pos = np.zeros((n, 3), np.float32)
+        nrm = np.zeros((n, 3), np.float32)
+        self._check(self.lib.pt_cast_rays(self.ctx, fptr(o), fptr(d), n, iptr(ids), fptr(pos), fptr(nrm)), "pt_cast_rays")
+        return ids, pos, nrm
+
+    def present_srgb8(self):
+        s = self.settings
+        out = np.zeros((s.height, s.width, 3), np.uint8)
+        self._check(self.lib.pt_present_srgb8(self.ctx, u8ptr(out)), "pt_present_srgb8")
+        return out

@@ -1,0 +1,686 @@
+// libptcore: context, device memory and the C ABI of include/pt_api.h.
+// All computation on the render path happens in the HIP kernels of pt_kernels.hip; this file only
+// prepares inputs (pt_host.cpp), moves memory and sequences launches.  There is no CPU fallback:
+// without a working HIP device every entry point that renders returns PT_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "pt_api.h"
+#include "pt_host.h"
+#include "pt_launch.h"
+
+namespace {
+
+std::string g_create_error;
+
+struct DevBuf {
+	void* p = nullptr;
+	size_t cap = 0;
+	hipError_t reserve(size_t bytes) {
+		if(bytes <= cap) return hipSuccess;
+		if(p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if(e != hipSuccess) return e; }
+		size_t want = bytes < 256 ? 256 : bytes;
+		hipError_t e = hipMalloc(&p, want);
+		if(e == hipSuccess) cap = want;
+		return e;
+	}
+	void release() { if(p) (void)hipFree(p); p = nullptr; cap = 0; }
+	template <typename T> T* as() const { return (T*)p; }
+};
+
+ptl::Vec vec(pt::f3 v) { return { v.x, v.y, v.z }; }
+
+}  // namespace
+
+struct pt_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr, side = nullptr;
+	std::string err;
+	std::mutex mu;                       // guards err and the launch bookkeeping
+
+	// inputs (deep copies)
+	pt_world world{};
+	pt_settings st{};
+	std::vector<pt_object> objs;
+	bool prepared = false;
+
+	// device-resident scene
+	DevBuf geo, mat, cell_start, cell_items, dirs, disc, samples, offsets, fb, accum, counter, stats_dev, scratch;
+	uint32_t* abort_flag = nullptr;      // host-pinned, read by the trace kernel
+	uint32_t* abort_flag_dev = nullptr;  // the same word as the device addresses it
+	uint32_t* counter_host = nullptr;    // host-pinned landing word for progress polls
+	ptl::TraceJob job{};
+	size_t fb_floats = 0;
+	int local_tiles = 0;
+
+	// launch bookkeeping
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // events of launches not yet synchronised
+	std::vector<hipEvent_t> event_pool;
+	double kernel_ms_sum = 0;
+	int kernel_launches = 0;
+	pt_stats stats{};
+
+	// asynchronous render (pt_render_start)
+	std::thread worker;
+	std::atomic<int> active{ 0 }, done{ 0 }, aborted{ 0 }, status{ 0 };
+	std::chrono::steady_clock::time_point t_start, t_end;
+	float* user_rgb = nullptr;
+};
+
+namespace {
+
+int fail(pt_ctx* c, int code, const char* fmt, ...) {
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	if(c) { std::lock_guard<std::mutex> l(c->mu); c->err = buf; }
+	else g_create_error = buf;
+	return code;
+}
+
+#define PT_HIP(c, call) do { hipError_t e_ = (call); if(e_ != hipSuccess) return fail((c), PT_ERR_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); } while(0)
+
+hipEvent_t take_event(pt_ctx* c) {
+	if(!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+	hipEvent_t e = nullptr;
+	if(hipEventCreate(&e) != hipSuccess) return nullptr;
+	return e;
+}
+
+int validate(pt_ctx* c, const pt_world* w, const pt_object* objs, int n, const pt_settings* s) {
+	if(!w || !s || (n > 0 && !objs) || n < 0) return fail(c, PT_ERR_ARG, "null or negative argument");
+	if(s->width < 1 || s->height < 1 || s->width > 16384 || s->height > 16384) return fail(c, PT_ERR_LIMIT, "image size %dx%d outside 1..16384", s->width, s->height);
+	if(s->spp_wanted < 1) return fail(c, PT_ERR_ARG, "spp_wanted must be >= 1");
+	if(s->sample_grid_width < 1 || s->sample_grid_width > 4) return fail(c, PT_ERR_LIMIT, "sample_grid_width %d outside 1..4", s->sample_grid_width);
+	if(s->max_bounces < 1) return fail(c, PT_ERR_ARG, "max_bounces must be >= 1");
+	if(s->grid_hint < 1 || s->grid_hint > 512) return fail(c, PT_ERR_LIMIT, "grid_hint %d outside 1..512", s->grid_hint);
+	if(s->seed_policy != PT_SEED_PER_SAMPLE) return fail(c, PT_ERR_ARG, "the device path implements seed policy PT_SEED_PER_SAMPLE only");
+	if(s->part_count < 1 || s->part_index < 0 || s->part_index >= s->part_count) return fail(c, PT_ERR_ARG, "bad partition %d of %d", s->part_index, s->part_count);
+	if(s->frame_index < -1) return fail(c, PT_ERR_ARG, "frame_index must be >= -1");
+	for(int i = 0; i < n; i++) {
+		if(objs[i].type < PT_GEOM_SPHERE || objs[i].type > PT_GEOM_CONE)
+			return fail(c, PT_ERR_ARG, "object %d: geometry type %d is not supported on the device (sphere, box, cylinder, cone)", i, objs[i].type);
+	}
+	return PT_OK;
+}
+
+int upload(pt_ctx* c, DevBuf& b, const void* src, size_t bytes) {
+	PT_HIP(c, b.reserve(bytes));
+	if(bytes) PT_HIP(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+	return PT_OK;
+}
+
+// pt_prepare body; the caller holds no lock and has set the device.
+int prepare(pt_ctx* c) {
+	auto t0 = std::chrono::steady_clock::now();
+	const pt_settings& s = c->st;
+	const int n = (int)c->objs.size();
+
+	std::vector<float> rec((size_t)(n > 0 ? n : 1) * PT_F_STRIDE, 0.0f);
+	pt::flatten_objects(c->objs.data(), n, rec.data());
+	pt::WorldConsts wc;
+	pt::world_consts(c->world, s.width, s.height, &wc);
+
+	// tables, then blue noise, from PCG stream (0, seed): the order the application draws them in
+	pt::Pcg rng;
+	rng.seed(0, s.seed);
+	std::vector<pt::f3> dirs(PT_TABLE_COUNT);
+	std::vector<pt::f2> disc(PT_TABLE_COUNT);
+	pt::make_tables(rng, dirs.data(), disc.data());
+	std::vector<pt::f2> samples;
+	std::vector<int32_t> offsets;
+	pt::make_samples(rng, s.spp_wanted, s.sample_grid_width, &samples, &offsets);
+	for(size_t t = 0; t + 1 < offsets.size(); t++)
+		if(offsets[t + 1] - offsets[t] > 4096) return fail(c, PT_ERR_LIMIT, "a pixel tile holds %d samples, more than the 4096 the per-sample streams allow", offsets[t + 1] - offsets[t]);
+
+	pt::GridDesc gd{};
+	std::vector<uint32_t> cell_start, cell_items;
+	bool have_grid = pt::build_grid(rec.data(), n, s.grid_hint, &gd, &cell_start, &cell_items);
+	if(!have_grid) {
+		if(n > 0) return fail(c, PT_ERR_LIMIT, "the scene's extent gives an unusable grid (non-finite bounds or more than 2^28 cells)");
+		gd = pt::GridDesc{ { 0, 0, 0 }, { 1, 1, 1 }, { 1, 1, 1 } };
+		cell_start.assign(2, 0);
+		cell_items.clear();
+	}
+
+	// structure-of-arrays planes of float4 (layout documented in pt_device.h)
+	const size_t np = (size_t)(n > 0 ? n : 1);
+	std::vector<float> geo(np * 6 * 4, 0.0f), mat(np * 2 * 4, 0.0f);
+	for(int i = 0; i < n; i++) {
+		const float* r = rec.data() + (size_t)i * PT_F_STRIDE;
+		int32_t type, flags;
+		memcpy(&type, r + PT_F_TYPE, 4);
+		memcpy(&flags, r + PT_F_FLAGS, 4);
+		int32_t tf = type | (flags << 8);
+		float tf_bits;
+		memcpy(&tf_bits, &tf, 4);
+		auto plane = [&](std::vector<float>& v, int p) { return v.data() + ((size_t)p * np + (size_t)i) * 4; };
+		float* g0 = plane(geo, 0); g0[0] = r[PT_F_POS]; g0[1] = r[PT_F_POS + 1]; g0[2] = r[PT_F_POS + 2]; g0[3] = r[PT_F_BRADIUS];
+		memcpy(plane(geo, 1), r + PT_F_ROT, 16);
+		memcpy(plane(geo, 2), r + PT_F_ROTINV, 16);
+		float* g3 = plane(geo, 3); g3[0] = r[PT_F_DIM]; g3[1] = r[PT_F_DIM + 1]; g3[2] = r[PT_F_DIM + 2]; g3[3] = tf_bits;
+		float* g4 = plane(geo, 4); g4[0] = r[PT_F_SCALE]; g4[1] = r[PT_F_SCALE + 1]; g4[2] = r[PT_F_SCALE + 2]; g4[3] = r[PT_F_ROUGH];
+		float* g5 = plane(geo, 5); g5[0] = r[PT_F_SCALEINV]; g5[1] = r[PT_F_SCALEINV + 1]; g5[2] = r[PT_F_SCALEINV + 2]; g5[3] = 0;
+		float* m0 = plane(mat, 0); m0[0] = r[PT_F_COLOR]; m0[1] = r[PT_F_COLOR + 1]; m0[2] = r[PT_F_COLOR + 2]; m0[3] = r[PT_F_REFL];
+		float* m1 = plane(mat, 1); m1[0] = r[PT_F_EMIT]; m1[1] = r[PT_F_EMIT + 1]; m1[2] = r[PT_F_EMIT + 2]; m1[3] = r[PT_F_IOR];
+	}
+	std::vector<float> dirs4((size_t)PT_TABLE_COUNT * 4, 0.0f);
+	for(int i = 0; i < PT_TABLE_COUNT; i++) { dirs4[(size_t)i * 4] = dirs[(size_t)i].x; dirs4[(size_t)i * 4 + 1] = dirs[(size_t)i].y; dirs4[(size_t)i * 4 + 2] = dirs[(size_t)i].z; }
+
+	int rc;
+	if((rc = upload(c, c->geo, geo.data(), geo.size() * 4))) return rc;
+	if((rc = upload(c, c->mat, mat.data(), mat.size() * 4))) return rc;
+	if((rc = upload(c, c->cell_start, cell_start.data(), cell_start.size() * 4))) return rc;
+	if((rc = upload(c, c->cell_items, cell_items.data(), cell_items.size() * 4))) return rc;
+	if((rc = upload(c, c->dirs, dirs4.data(), dirs4.size() * 4))) return rc;
+	if((rc = upload(c, c->disc, disc.data(), disc.size() * sizeof(pt::f2)))) return rc;
+	if((rc = upload(c, c->samples, samples.data(), samples.size() * sizeof(pt::f2)))) return rc;
+	if((rc = upload(c, c->offsets, offsets.data(), offsets.size() * 4))) return rc;
+
+	// image tiling and this context's partition
+	const int tiles_x = (s.width + 7) / 8, tiles_y = (s.height + 7) / 8;
+	const int tiles = tiles_x * tiles_y;
+	c->local_tiles = (tiles - s.part_index + s.part_count - 1) / s.part_count;
+	const bool compact = s.part_count > 1;
+	c->fb_floats = compact ? (size_t)c->local_tiles * 64 * 3 : (size_t)s.width * s.height * 3;
+	PT_HIP(c, c->fb.reserve(c->fb_floats * 4));
+	if(s.frame_index >= 0) PT_HIP(c, c->accum.reserve(c->fb_floats * 4));
+	PT_HIP(c, c->counter.reserve(256));
+	PT_HIP(c, c->stats_dev.reserve(256));
+	PT_HIP(c, hipMemsetAsync(c->stats_dev.p, 0, 256, c->stream));
+
+	ptl::TraceJob& j = c->job;
+	j = ptl::TraceJob{};
+	j.scene.geo = c->geo.as<float4>();
+	j.scene.mat = c->mat.as<float4>();
+	j.scene.cell_start = c->cell_start.as<uint32_t>();
+	j.scene.cell_items = c->cell_items.as<uint32_t>();
+	j.scene.dirs = c->dirs.as<float4>();
+	j.scene.disc = c->disc.as<float2>();
+	j.scene.samples = c->samples.as<float2>();
+	j.scene.offsets = c->offsets.as<int32_t>();
+	j.scene.n = n;
+	j.scene.brute = n < s.brute_force_below ? 1 : 0;
+	for(int k = 0; k < 3; k++) { j.scene.grid.cmin[k] = gd.coord_min[k]; j.scene.grid.cnt[k] = gd.cell_count[k]; j.scene.grid.cs[k] = gd.cell_size[k]; }
+
+	// per-job constants of the tile job (code/raycast.cpp:1010-1021), evaluated once on the host
+	ptl::FrameDev& f = j.frame;
+	auto mul = [](pt::f3 a, float b) { return pt::f3{ a.x * b, a.y * b, a.z * b }; };
+	pt::f3 down = { -wc.cam_up.x, -wc.cam_up.y, -wc.cam_up.z };
+	pt::f3 back = { -wc.cam_dir.x, -wc.cam_dir.y, -wc.cam_dir.z };
+	f.cam_pos = vec(wc.cam_pos); f.cam_dir = vec(wc.cam_dir); f.right = vec(wc.cam_right); f.down = vec(down); f.back = vec(back);
+	f.right_width = vec(mul(wc.cam_right, wc.dim_w));
+	f.down_height = vec(mul(down, wc.dim_h));
+	f.right_px = vec(mul(mul(wc.cam_right, wc.dim_w), (1.0f / s.width)));
+	f.down_px = vec(mul(mul(down, wc.dim_h), (1.0f / s.height)));
+	f.top_left = vec(wc.top_left);
+	{
+		float len = sqrtf(wc.light_dir.x * wc.light_dir.x + wc.light_dir.y * wc.light_dir.y + wc.light_dir.z * wc.light_dir.z);
+		f.light_dir = { wc.light_dir.x / len, wc.light_dir.y / len, wc.light_dir.z / len };
+	}
+	f.bg = vec(wc.bg); f.ambient = vec(wc.ambient); f.light = vec(wc.light);
+	f.focal_distance = wc.focal_distance; f.aperture = wc.aperture;
+	f.width = s.width; f.height = s.height; f.tile_w = s.sample_grid_width;
+	f.max_bounces = s.max_bounces;
+	f.seed = s.seed;
+
+	j.fb = c->fb.as<float>();
+	j.accum = s.frame_index >= 0 ? c->accum.as<float>() : nullptr;
+	j.group_counter = c->counter.as<uint32_t>();
+	j.abort_flag = c->abort_flag_dev;
+	j.stats = c->stats_dev.as<uint64_t>();
+	j.tiles_x = tiles_x; j.tiles_y = tiles_y;
+	j.n_groups = c->local_tiles;
+	j.part_index = s.part_index; j.part_count = s.part_count;
+	j.frame_index = s.frame_index;
+	j.compact = compact ? 1 : 0;
+
+	// exact path count of this partition (code/raycast.cpp:1045-1048 summed over its pixels)
+	pt_stats& st = c->stats;
+	st = pt_stats{};
+	const int gw = s.sample_grid_width;
+	uint64_t paths = 0, pixels = 0, empty = 0;
+	for(int lt = 0; lt < c->local_tiles; lt++) {
+		int tile = lt * s.part_count + s.part_index;
+		int x0 = (tile % tiles_x) * 8, y0 = (tile / tiles_x) * 8;
+		for(int yy = y0; yy < y0 + 8 && yy < s.height; yy++) for(int xx = x0; xx < x0 + 8 && xx < s.width; xx++) {
+			int t = (yy % gw) * gw + (xx % gw);
+			int cnt = offsets[(size_t)t + 1] - offsets[(size_t)t];
+			pixels++;
+			if(cnt == 0) empty++;
+			else paths += s.frame_index >= 0 ? 1u : (uint64_t)cnt;
+		}
+	}
+	st.paths = paths; st.pixels = pixels; st.zero_sample_pixels = empty;
+	st.samples_total = (int)samples.size();
+	st.objects = n;
+	for(int k = 0; k < 3; k++) { st.cells[k] = gd.cell_count[k]; st.cell_size[k] = gd.cell_size[k]; }
+	st.cell_items = (int)cell_items.size();
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	st.prepare_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	c->prepared = true;
+	return PT_OK;
+}
+
+int trace(pt_ctx* c, float* d_rgb, hipStream_t stream, bool sync) {
+	if(!c->prepared) return fail(c, PT_ERR_STATE, "pt_trace before pt_prepare");
+	ptl::TraceJob job = c->job;
+	if(d_rgb) job.fb = d_rgb;
+	hipStream_t s = stream ? stream : c->stream;
+	hipEvent_t e0 = take_event(c), e1 = take_event(c);
+	if(!e0 || !e1) return fail(c, PT_ERR_DEVICE, "hipEventCreate failed");
+	PT_HIP(c, hipEventRecord(e0, s));
+	int blocks = 0;
+	PT_HIP(c, ptl::launch_trace(job, s, &blocks));
+	PT_HIP(c, hipEventRecord(e1, s));
+	{
+		std::lock_guard<std::mutex> l(c->mu);
+		c->pending.push_back({ e0, e1 });
+		c->stats.bounce_passes = 1;
+	}
+	if(sync) {
+		PT_HIP(c, hipStreamSynchronize(s));
+	}
+	return PT_OK;
+}
+
+// Folds the events of finished launches into the statistics. The caller has synchronised.
+int collect(pt_ctx* c) {
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> pend;
+	{ std::lock_guard<std::mutex> l(c->mu); pend.swap(c->pending); }
+	double sum = 0;
+	for(auto& p : pend) {
+		float ms = 0;
+		PT_HIP(c, hipEventSynchronize(p.second));
+		PT_HIP(c, hipEventElapsedTime(&ms, p.first, p.second));
+		sum += ms;
+		c->event_pool.push_back(p.first);
+		c->event_pool.push_back(p.second);
+	}
+	if(!pend.empty()) {
+		c->kernel_ms_sum = sum;
+		c->kernel_launches = (int)pend.size();
+		c->stats.trace_ms = (float)(sum / pend.size());
+		c->stats.dominant_kernel_ms = c->stats.trace_ms;
+		uint64_t rays = 0;
+		PT_HIP(c, hipMemcpy(&rays, c->stats_dev.p, sizeof rays, hipMemcpyDeviceToHost));
+		c->stats.rays = rays / (uint64_t)pend.size();
+		PT_HIP(c, hipMemset(c->stats_dev.p, 0, 256));
+	}
+	return PT_OK;
+}
+
+int download(pt_ctx* c, float* rgb) {
+	if(!c->prepared) return fail(c, PT_ERR_STATE, "pt_download before pt_prepare");
+	if(!rgb) return fail(c, PT_ERR_ARG, "null output");
+	const pt_settings& s = c->st;
+	if(s.part_count == 1) {
+		PT_HIP(c, hipMemcpy(rgb, c->fb.p, c->fb_floats * 4, hipMemcpyDeviceToHost));
+		return PT_OK;
+	}
+	// tile-major partition buffer -> the caller's row-major image; other partitions' pixels are left alone
+	std::vector<float> tmp(c->fb_floats);
+	PT_HIP(c, hipMemcpy(tmp.data(), c->fb.p, c->fb_floats * 4, hipMemcpyDeviceToHost));
+	const int tiles_x = (s.width + 7) / 8;
+	for(int lt = 0; lt < c->local_tiles; lt++) {
+		int tile = lt * s.part_count + s.part_index;
+		int x0 = (tile % tiles_x) * 8, y0 = (tile / tiles_x) * 8;
+		for(int j = 0; j < 64; j++) {
+			int x = x0 + (j & 7), y = y0 + (j >> 3);
+			if(x >= s.width || y >= s.height) continue;
+			memcpy(rgb + ((size_t)y * s.width + x) * 3, tmp.data() + ((size_t)lt * 64 + j) * 3, 12);
+		}
+	}
+	return PT_OK;
+}
+
+void worker_main(pt_ctx* c) {
+	int rc = PT_OK;
+	if(hipSetDevice(c->device) != hipSuccess) rc = fail(c, PT_ERR_DEVICE, "hipSetDevice(%d) failed", c->device);
+	if(rc == PT_OK) rc = prepare(c);
+	if(rc == PT_OK) rc = trace(c, nullptr, nullptr, true);
+	if(rc == PT_OK) rc = collect(c);
+	if(rc == PT_OK) rc = download(c, c->user_rgb);
+	c->aborted.store(*c->abort_flag != 0 ? 1 : 0);
+	c->t_end = std::chrono::steady_clock::now();
+	c->status.store(rc);
+	c->done.store(1);
+}
+
+void join_worker(pt_ctx* c) {
+	if(c->worker.joinable()) c->worker.join();
+	c->active.store(0);
+}
+
+}  // namespace
+
+extern "C" {
+
+pt_ctx* pt_create(int device) {
+	int count = 0;
+	hipError_t e = hipGetDeviceCount(&count);
+	if(e != hipSuccess || count <= 0) { fail(nullptr, PT_ERR_DEVICE, "no HIP device: %s", hipGetErrorString(e)); return nullptr; }
+	if(device < 0 || device >= count) { fail(nullptr, PT_ERR_ARG, "device %d outside 0..%d", device, count - 1); return nullptr; }
+	if((e = hipSetDevice(device)) != hipSuccess) { fail(nullptr, PT_ERR_DEVICE, "hipSetDevice: %s", hipGetErrorString(e)); return nullptr; }
+	pt_ctx* c = new pt_ctx();
+	c->device = device;
+	bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+	          hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess &&
+	          hipHostMalloc((void**)&c->abort_flag, 64, hipHostMallocMapped) == hipSuccess &&
+	          hipHostMalloc((void**)&c->counter_host, 64, hipHostMallocDefault) == hipSuccess;
+	if(!ok) { fail(nullptr, PT_ERR_DEVICE, "stream / pinned memory creation failed: %s", hipGetErrorString(hipGetLastError())); pt_destroy(c); return nullptr; }
+	*c->abort_flag = 0;
+	*c->counter_host = 0;
+	if(hipHostGetDevicePointer((void**)&c->abort_flag_dev, c->abort_flag, 0) != hipSuccess) c->abort_flag_dev = c->abort_flag;
+	return c;
+}
+
+void pt_destroy(pt_ctx* c) {
+	if(!c) return;
+	if(c->active.load()) { *c->abort_flag = 1; join_worker(c); }
+	(void)hipSetDevice(c->device);
+	if(c->stream) (void)hipStreamSynchronize(c->stream);
+	for(DevBuf* b : { &c->geo, &c->mat, &c->cell_start, &c->cell_items, &c->dirs, &c->disc, &c->samples, &c->offsets, &c->fb, &c->accum, &c->counter, &c->stats_dev, &c->scratch }) b->release();
+	for(auto& p : c->pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+	for(hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+	if(c->abort_flag) (void)hipHostFree(c->abort_flag);
+	if(c->counter_host) (void)hipHostFree(c->counter_host);
+	if(c->stream) (void)hipStreamDestroy(c->stream);
+	if(c->side) (void)hipStreamDestroy(c->side);
+	delete c;
+}
+
+const char* pt_last_error(const pt_ctx* c) {
+	if(!c) return g_create_error.c_str();
+	return c->err.c_str();
+}
+
+void pt_default_settings(pt_settings* s) {
+	if(!s) return;
+	memset(s, 0, sizeof *s);
+	s->width = 768; s->height = 432;           // code/app.cpp:639
+	s->spp_wanted = 100;                       // code/app.cpp:641
+	s->sample_grid_width = 3;                  // code/app.cpp:642
+	s->max_bounces = 10;                       // code/app.cpp:643
+	s->grid_hint = 10;                         // code/app.cpp:1276
+	s->brute_force_below = 10;                 // code/raycast.cpp:1100
+	s->seed_policy = PT_SEED_PER_SAMPLE;
+	s->seed = 12345;
+	s->part_index = 0; s->part_count = 1;
+	s->frame_index = -1;
+}
+
+int pt_default_scene(pt_world* w, pt_object* o, int capacity, int* count) {
+	if(!w || !o || capacity < 2) return PT_ERR_ARG;
+	memset(w, 0, sizeof *w);
+	memset(o, 0, sizeof(pt_object) * 2);
+	w->camera.pos[0] = 0; w->camera.pos[1] = -30; w->camera.pos[2] = 7;
+	w->camera.fov = 90; w->camera.plane_width = 10;
+	for(int k = 0; k < 3; k++) { w->background_color[k] = 1; w->ambient_color[k] = 1; w->light_color[k] = 1; }
+	w->light_rot[0] = 0; w->light_rot[1] = 90;
+	w->focal_distance = 30; w->aperture = 0;
+	// ground box
+	o[0].pos[2] = 0.1f; o[0].rot[0] = 1; o[0].dim[0] = 50; o[0].dim[1] = 50; o[0].dim[2] = 0.01f;
+	o[0].color[0] = o[0].color[1] = o[0].color[2] = 0.5f; o[0].type = PT_GEOM_BOX; o[0].refractive_index = 1;
+	// mirror sphere
+	o[1].pos[2] = 7; o[1].rot[0] = 1; o[1].dim[0] = o[1].dim[1] = o[1].dim[2] = 8;
+	o[1].color[0] = o[1].color[1] = o[1].color[2] = 0.7f; o[1].type = PT_GEOM_SPHERE; o[1].reflection_mod = 1; o[1].refractive_index = 1;
+	if(count) *count = 2;
+	return PT_OK;
+}
+
+static int store_inputs(pt_ctx* c, const pt_world* w, const pt_object* objs, int n, const pt_settings* s) {
+	int rc = validate(c, w, objs, n, s);
+	if(rc) return rc;
+	c->world = *w;
+	c->st = *s;
+	c->objs.assign(objs, objs + n);
+	c->prepared = false;
+	return PT_OK;
+}
+
+int pt_prepare(pt_ctx* c, const pt_world* w, const pt_object* objs, int n, const pt_settings* s) {
+	if(!c) return PT_ERR_ARG;
+	if(c->active.load() && !c->done.load()) return fail(c, PT_ERR_BUSY, "a render is active");
+	if(c->active.load()) join_worker(c);
+	int rc = store_inputs(c, w, objs, n, s);
+	if(rc) return rc;
+	PT_HIP(c, hipSetDevice(c->device));
+	*c->abort_flag = 0;
+	return prepare(c);
+}
+
+int pt_trace(pt_ctx* c, float* d_rgb, void* hip_stream, int sync) {
+	if(!c) return PT_ERR_ARG;
+	if(c->active.load() && !c->done.load()) return fail(c, PT_ERR_BUSY, "a render is active");
+	PT_HIP(c, hipSetDevice(c->device));
+	int rc = trace(c, d_rgb, (hipStream_t)hip_stream, sync != 0);
+	if(rc == PT_OK && sync) rc = collect(c);
+	return rc;
+}
+
+int pt_sync(pt_ctx* c) {
+	if(!c) return PT_ERR_ARG;
+	PT_HIP(c, hipSetDevice(c->device));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	return collect(c);
+}
+
+int pt_set_frame(pt_ctx* c, int frame_index) {
+	if(!c) return PT_ERR_ARG;
+	if(!c->prepared) return fail(c, PT_ERR_STATE, "pt_set_frame before pt_prepare");
+	if(frame_index < 0 || c->st.frame_index < 0) return fail(c, PT_ERR_ARG, "progressive mode needs a scene prepared with frame_index >= 0");
+	c->st.frame_index = frame_index;
+	c->job.frame_index = frame_index;
+	return PT_OK;
+}
+
+int pt_download(pt_ctx* c, float* rgb) {
+	if(!c) return PT_ERR_ARG;
+	PT_HIP(c, hipSetDevice(c->device));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	return download(c, rgb);
+}
+
+int pt_get_stats(const pt_ctx* c, pt_stats* out) {
+	if(!c || !out) return PT_ERR_ARG;
+	*out = c->stats;
+	return PT_OK;
+}
+
+int pt_render_start(pt_ctx* c, const pt_world* w, const pt_object* objs, int n, const pt_settings* s, float* rgb) {
+	if(!c) return PT_ERR_ARG;
+	if(!rgb) return fail(c, PT_ERR_ARG, "null output buffer");
+	if(c->active.load() && !c->done.load()) return fail(c, PT_ERR_BUSY, "a render is already active");
+	if(c->active.load()) join_worker(c);
+	int rc = store_inputs(c, w, objs, n, s);
+	if(rc) return rc;
+	c->user_rgb = rgb;
+	*c->abort_flag = 0;
+	c->done.store(0); c->aborted.store(0); c->status.store(0);
+	c->t_start = std::chrono::steady_clock::now();
+	c->active.store(1);
+	c->worker = std::thread(worker_main, c);
+	return PT_OK;
+}
+
+int pt_render_progress(pt_ctx* c, pt_progress* info) {
+	if(!c || !info) return PT_ERR_ARG;
+	memset(info, 0, sizeof *info);
+	if(!c->active.load()) return fail(c, PT_ERR_STATE, "no render was started");
+	auto now = std::chrono::steady_clock::now();
+	if(c->done.load()) {
+		info->done = 1;
+		info->aborted = c->aborted.load();
+		info->fraction = info->aborted ? 0.0f : 1.0f;
+		info->seconds = std::chrono::duration<double>(c->t_end - c->t_start).count();
+		info->paths_done = info->aborted ? 0 : c->stats.paths;
+		return c->status.load();
+	}
+	info->seconds = std::chrono::duration<double>(now - c->t_start).count();
+	// tiles handed out so far: read the device counter through the side stream while the kernel runs
+	if(c->prepared && c->local_tiles > 0 && hipSetDevice(c->device) == hipSuccess &&
+	   hipMemcpyAsync(c->counter_host, c->counter.p, 4, hipMemcpyDeviceToHost, c->side) == hipSuccess &&
+	   hipStreamSynchronize(c->side) == hipSuccess) {
+		uint32_t got = *c->counter_host;
+		float f = (float)got / (float)c->local_tiles;
+		info->fraction = f > 1 ? 1 : f;
+		info->paths_done = (uint64_t)((double)c->stats.paths * info->fraction);
+	}
+	return PT_OK;
+}
+
+int pt_render_abort(pt_ctx* c) {
+	if(!c) return PT_ERR_ARG;
+	if(!c->active.load()) return fail(c, PT_ERR_STATE, "no render was started");
+	*c->abort_flag = 1;     // the trace kernel stops fetching tiles; pixels already in flight finish
+	return PT_OK;
+}
+
+int pt_render_wait(pt_ctx* c) {
+	if(!c) return PT_ERR_ARG;
+	if(!c->active.load()) return fail(c, PT_ERR_STATE, "no render was started");
+	join_worker(c);
+	c->active.store(1);     // keep the finished render pollable until the next start
+	return c->status.load();
+}
+
+int pt_debug_primary(pt_ctx* c, int32_t* hit_id, uint64_t* cell_hash) {
+	if(!c) return PT_ERR_ARG;
+	if(!c->prepared) return fail(c, PT_ERR_STATE, "pt_debug_primary before pt_prepare");
+	PT_HIP(c, hipSetDevice(c->device));
+	size_t n = (size_t)c->st.width * c->st.height;
+	size_t hash_at = ((n * 4 + 255) / 256) * 256;
+	PT_HIP(c, c->scratch.reserve(hash_at + n * 8));
+	int32_t* d_id = c->scratch.as<int32_t>();
+	uint64_t* d_hash = (uint64_t*)((char*)c->scratch.p + hash_at);
+	PT_HIP(c, ptl::launch_primary_aov(c->job.scene, c->job.frame, d_id, d_hash, c->stream));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	if(hit_id) PT_HIP(c, hipMemcpy(hit_id, d_id, n * 4, hipMemcpyDeviceToHost));
+	if(cell_hash) PT_HIP(c, hipMemcpy(cell_hash, d_hash, n * 8, hipMemcpyDeviceToHost));
+	return PT_OK;
+}
+
+int pt_cast_rays(pt_ctx* c, const float* origins, const float* dirs, int n, int32_t* hit_id, float* hit_pos, float* hit_nrm) {
+	if(!c) return PT_ERR_ARG;
+	if(!c->prepared) return fail(c, PT_ERR_STATE, "pt_cast_rays before pt_prepare");
+	if(n < 0 || (n > 0 && (!origins || !dirs || !hit_id))) return fail(c, PT_ERR_ARG, "null argument");
+	if(n == 0) return PT_OK;
+	PT_HIP(c, hipSetDevice(c->device));
+	size_t v = (size_t)n * 12;
+	PT_HIP(c, c->scratch.reserve(v * 4 + (size_t)n * 4 + 1024));
+	char* base = (char*)c->scratch.p;
+	float* d_o = (float*)base; float* d_d = (float*)(base + v); float* d_p = (float*)(base + 2 * v); float* d_n = (float*)(base + 3 * v);
+	int32_t* d_id = (int32_t*)(base + 4 * v);
+	PT_HIP(c, hipMemcpyAsync(d_o, origins, v, hipMemcpyHostToDevice, c->stream));
+	PT_HIP(c, hipMemcpyAsync(d_d, dirs, v, hipMemcpyHostToDevice, c->stream));
+	PT_HIP(c, ptl::launch_cast(c->job.scene, d_o, d_d, n, d_id, d_p, d_n, c->stream));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	PT_HIP(c, hipMemcpy(hit_id, d_id, (size_t)n * 4, hipMemcpyDeviceToHost));
+	if(hit_pos) PT_HIP(c, hipMemcpy(hit_pos, d_p, v, hipMemcpyDeviceToHost));
+	if(hit_nrm) PT_HIP(c, hipMemcpy(hit_nrm, d_n, v, hipMemcpyDeviceToHost));
+	return PT_OK;
+}
+
+int pt_present_srgb8(pt_ctx* c, uint8_t* rgb8) {
+	if(!c) return PT_ERR_ARG;
+	if(!c->prepared) return fail(c, PT_ERR_STATE, "pt_present_srgb8 before pt_prepare");
+	if(!rgb8) return fail(c, PT_ERR_ARG, "null output");
+	if(c->st.part_count != 1) return fail(c, PT_ERR_STATE, "pt_present_srgb8 works on a whole image (part_count == 1)");
+	PT_HIP(c, hipSetDevice(c->device));
+	PT_HIP(c, c->scratch.reserve(c->fb_floats));
+	PT_HIP(c, ptl::launch_srgb8(c->fb.as<float>(), c->fb_floats, c->scratch.as<uint8_t>(), c->stream));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	PT_HIP(c, hipMemcpy(rgb8, c->scratch.p, c->fb_floats, hipMemcpyDeviceToHost));
+	return PT_OK;
+}
+
+int pt_assemble(pt_ctx* c, const float* d_parts, size_t stride_floats, int part_count, int width, int height, float* d_rgb, void* hip_stream) {
+	if(!c) return PT_ERR_ARG;
+	if(!d_parts || !d_rgb || part_count < 1 || width < 1 || height < 1) return fail(c, PT_ERR_ARG, "bad argument");
+	PT_HIP(c, hipSetDevice(c->device));
+	hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+	PT_HIP(c, ptl::launch_assemble(d_parts, stride_floats, part_count, width, height, d_rgb, s));
+	return PT_OK;
+}
+
+int pt_partition_floats(const pt_ctx* c, size_t* floats) {
+	if(!c || !floats) return PT_ERR_ARG;
+	*floats = c->fb_floats;
+	return PT_OK;
+}
+
+/* ---- host stages --------------------------------------------------------------------------------- */
+
+int pt_host_flatten(const pt_object* objs, int n, float* records) {
+	if(n < 0 || (n > 0 && (!objs || !records))) return PT_ERR_ARG;
+	pt::flatten_objects(objs, n, records);
+	return PT_OK;
+}
+
+int pt_host_world(const pt_world* w, int width, int height, float* out) {
+	if(!w || !out || width < 1 || height < 1) return PT_ERR_ARG;
+	pt::WorldConsts wc;
+	pt::world_consts(*w, width, height, &wc);
+	memset(out, 0, sizeof(float) * PT_W_COUNT);
+	out[PT_W_DIMH] = wc.dim_h; out[PT_W_NEAR] = wc.near_dist;
+	auto put = [&](int at, pt::f3 v) { out[at] = v.x; out[at + 1] = v.y; out[at + 2] = v.z; };
+	put(PT_W_DIR, wc.cam_dir); put(PT_W_UP, wc.cam_up); put(PT_W_RIGHT, wc.cam_right); put(PT_W_TOPLEFT, wc.top_left);
+	put(PT_W_LIGHTDIR, wc.light_dir); put(PT_W_BG, wc.bg); put(PT_W_AMBIENT, wc.ambient); put(PT_W_LIGHT, wc.light);
+	return PT_OK;
+}
+
+int pt_host_tables(uint64_t seed, int spp_wanted, int grid_width, float* dirs, float* disc, float* samples, int sample_capacity,
+                   int32_t* offsets, int* sample_count) {
+	if(spp_wanted < 1 || grid_width < 1 || grid_width > 4) return PT_ERR_ARG;
+	pt::Pcg rng;
+	rng.seed(0, seed);
+	std::vector<pt::f3> d(PT_TABLE_COUNT);
+	std::vector<pt::f2> c(PT_TABLE_COUNT);
+	pt::make_tables(rng, d.data(), c.data());
+	std::vector<pt::f2> smp;
+	std::vector<int32_t> off;
+	pt::make_samples(rng, spp_wanted, grid_width, &smp, &off);
+	if(dirs) memcpy(dirs, d.data(), sizeof(pt::f3) * PT_TABLE_COUNT);
+	if(disc) memcpy(disc, c.data(), sizeof(pt::f2) * PT_TABLE_COUNT);
+	if(sample_count) *sample_count = (int)smp.size();
+	if(offsets) memcpy(offsets, off.data(), off.size() * 4);
+	if(samples) {
+		if((int)smp.size() > sample_capacity) return PT_ERR_LIMIT;
+		memcpy(samples, smp.data(), smp.size() * sizeof(pt::f2));
+	}
+	return PT_OK;
+}
+
+int pt_host_grid(const float* records, int n, int hint, int32_t* grid_ints, uint32_t* cell_start, int cell_capacity,
+                 uint32_t* cell_items, int item_capacity, int* cell_total, int* item_total) {
+	if(!records || n < 1 || hint < 1 || !grid_ints) return PT_ERR_ARG;
+	pt::GridDesc g{};
+	std::vector<uint32_t> start, items;
+	if(!pt::build_grid(records, n, hint, &g, &start, &items)) return PT_ERR_LIMIT;
+	for(int k = 0; k < 3; k++) { grid_ints[k] = g.coord_min[k]; grid_ints[3 + k] = g.cell_count[k]; grid_ints[6 + k] = g.cell_size[k]; }
+	if(cell_total) *cell_total = (int)g.cells();
+	if(item_total) *item_total = (int)items.size();
+	if(cell_start) {
+		if((int)start.size() > cell_capacity) return PT_ERR_LIMIT;
+		memcpy(cell_start, start.data(), start.size() * 4);
+	}
+	if(cell_items) {
+		if((int)items.size() > item_capacity) return PT_ERR_LIMIT;
+		if(!items.empty()) memcpy(cell_items, items.data(), items.size() * 4);
+	}
+	return PT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,565 @@
+// Device-side building blocks of the path tracer (gfx950).  Everything here is scalar IEEE fp32
+// per lane in the reference's operation order: compile with -ffp-contract=off and correctly rounded
+// divide/sqrt, never fast-math - primary-hit ids and DDA cell sequences are required to be
+// bit-identical to the CPU path (code/raycast.cpp:390-986, 991-1289).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pt_api.h"
+#include "pt_launch.h"
+
+#pragma clang fp contract(off)
+
+namespace ptd {
+
+#define PT_DEV __device__ __forceinline__
+
+using V3 = ptl::Vec;
+using Scene = ptl::SceneDev;
+using Frame = ptl::FrameDev;
+using Grid = ptl::GridDev;
+PT_DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_DEV V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_DEV V3 operator*(V3 a, float b) { return v3(a.x * b, a.y * b, a.z * b); }
+PT_DEV V3 operator/(V3 a, float b) { return v3(a.x / b, a.y / b, a.z / b); }
+PT_DEV V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+PT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PT_DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+PT_DEV float length(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+PT_DEV V3 normalise(V3 a) { return a / length(a); }          // divides, never multiplies by a reciprocal
+PT_DEV bool is_zero(V3 a) { return a.x == 0 && a.y == 0 && a.z == 0; }
+// The reference's min/max are ternaries (code/rt_math.cpp:60-74); they differ from fminf/fmaxf on NaN.
+PT_DEV float tmin(float a, float b) { return a <= b ? a : b; }
+PT_DEV float tmax(float a, float b) { return a >= b ? a : b; }
+PT_DEV float clamp_hi(float a, float hi) { return a > hi ? hi : a; }
+PT_DEV V3 clamp_hi(V3 a, float hi) { return v3(clamp_hi(a.x, hi), clamp_hi(a.y, hi), clamp_hi(a.z, hi)); }
+PT_DEV float blend(float t, float a, float b) {             // lerpCheck, code/rt_math.cpp:222-226
+	if(t == 0) return a;
+	else if(t == 1) return b;
+	else return a + t * (b - a);
+}
+PT_DEV V3 mirror(V3 dir, V3 n) {                            // reflectVector, code/rt_math.cpp:2405-2408
+	float k = 2 * dot(dir, n);
+	return dir - n * k;
+}
+PT_DEV bool inside_box(V3 p, V3 lo, V3 hi) {                // pointInBox, inclusive (code/rt_math.cpp:3340-3349)
+	return p.x >= lo.x && p.x <= hi.x && p.y >= lo.y && p.y <= hi.y && p.z >= lo.z && p.z <= hi.z;
+}
+PT_DEV V3 rotate(float4 q /* w,x,y,z */, V3 v) {            // Quat*Vec3, code/rt_math.cpp:2902-2907
+	V3 u = v3(q.y, q.z, q.w);
+	V3 c = cross(u, v);
+	V3 t = v3(c.x * 2, c.y * 2, c.z * 2);
+	return (v + t * q.x) + cross(u, t);
+}
+
+// ---- PCG32 (code/rt_misc.cpp:1152-1251) ----------------------------------------------------------
+struct Rng { uint64_t state, inc; };
+PT_DEV uint32_t rng_next(Rng& r) {
+	uint64_t old = r.state;
+	r.state = old * 6364136223846793005ULL + r.inc;
+	uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+	uint32_t rot = (uint32_t)(old >> 59u);
+	return (xs >> rot) | (xs << ((0u - rot) & 31));
+}
+PT_DEV void rng_seed(Rng& r, uint64_t initstate, uint64_t initseq) {
+	r.state = 0;
+	r.inc = (initseq << 1u) | 1u;
+	rng_next(r);
+	r.state += initstate;
+	rng_next(r);
+}
+template <uint32_t BOUND>
+PT_DEV uint32_t rng_bounded(Rng& r) {
+	constexpr uint32_t threshold = (0u - BOUND) % BOUND;
+	for(;;) {
+		uint32_t v = rng_next(r);
+		if(v >= threshold) return v % BOUND;
+	}
+}
+
+// ---- scene as the kernels see it ----------------------------------------------------------------
+// Entities are flattened into structure-of-arrays planes of float4, split by use: six geometry
+// planes read while intersecting and two material planes read once per hit.
+//   G0 pos.xyz | bounding-sphere radius     G1 rot (w,x,y,z)          G2 rotInverse (w,x,y,z)
+//   G3 dim.xyz | type + flags<<8 (int bits) G4 dimScale.xyz | roughness   G5 dimScaleInverse.xyz | -
+//   M0 colorLinear.rgb | reflectionMod      M1 emitColorLinear.rgb | refractiveIndex
+enum { G_POS = 0, G_ROT = 1, G_ROTINV = 2, G_DIM = 3, G_SCALE = 4, G_SCALEINV = 5, G_PLANES = 6, M_COLOR = 0, M_EMIT = 1, M_PLANES = 2 };
+enum { FLAG_ROTATED = 1, FLAG_EVEN = 2 };
+
+struct Hit { int id; V3 pos, nrm; };
+
+// ---- analytic intersectors (code/raycast.cpp:390-585) -------------------------------------------
+PT_DEV float hit_sphere(V3 lp, V3 ld, V3 sp, float sr, V3& pos, V3& nrm) {
+	V3 old = lp;
+	lp = lp - sp;
+	float d = dot(ld, lp);
+	float l = length(lp);
+	float b = d * d - l * l + sr * sr;
+	if(b < 0) return -1;
+	float distance = -(dot(ld, lp));
+	float sq = sqrtf(b);
+	if(distance - sq < 0) {
+		if(distance + sq < 0) return -1;
+		else distance += sq;
+	} else {
+		distance -= sq;
+	}
+	pos = old + ld * distance;
+	nrm = normalise(pos - sp);
+	return distance;
+}
+
+PT_DEV bool touches_sphere(V3 lp, V3 ld, V3 sp, float sr) {  // lineSphereCollision, code/rt_math.cpp:2361-2373
+	lp = lp - sp;
+	float d = dot(ld, lp);
+	float l = length(lp);
+	float b = d * d - l * l + sr * sr;
+	if(b < 0) return false;
+	float distance = -(dot(ld, lp)) + sqrtf(b);
+	if(distance < 0) return false;
+	return true;
+}
+
+PT_DEV float hit_box(V3 lp, V3 ld, V3 bpos, V3 bdim, V3& pos, V3& nrm) {
+	V3 half = bdim / 2;
+	V3 bmin = bpos - half;
+	V3 bmax = bpos + half;
+	float fx = 1.0f / ld.x, fy = 1.0f / ld.y, fz = 1.0f / ld.z;
+	float t1 = (bmin.x - lp.x) * fx;
+	float t2 = (bmax.x - lp.x) * fx;
+	float t3 = (bmin.y - lp.y) * fy;
+	float t4 = (bmax.y - lp.y) * fy;
+	float t5 = (bmin.z - lp.z) * fz;
+	float t6 = (bmax.z - lp.z) * fz;
+	float tn = tmax(tmax(tmin(t1, t2), tmin(t3, t4)), tmin(t5, t6));
+	float tf = tmin(tmin(tmax(t1, t2), tmax(t3, t4)), tmax(t5, t6));
+	if(tf < 0) return -1;
+	if(tn > tf) return -1;
+	float distance = tn < 0 ? tf : tn;
+	pos = lp + ld * distance;
+	if(distance == t1) nrm = v3(-1, 0, 0);
+	else if(distance == t2) nrm = v3(1, 0, 0);
+	else if(distance == t3) nrm = v3(0, -1, 0);
+	else if(distance == t4) nrm = v3(0, 1, 0);
+	else if(distance == t5) nrm = v3(0, 0, -1);
+	else if(distance == t6) nrm = v3(0, 0, 1);
+	else nrm = v3(0, 0, 0);
+	return distance;
+}
+
+PT_DEV float hit_cylinder(V3 p, V3 d, V3& pos, V3& nrm) {
+	float a = d.x * d.x + d.y * d.y;
+	float b = 2 * (p.x * d.x + p.y * d.y);
+	float c = (p.x * p.x + p.y * p.y) - 1;
+	float disc = b * b - 4 * a * c;
+	if(disc < 0) return -1;
+	float root = sqrtf(disc);
+	float t1 = (-b + root) / (2 * a);
+	float t2 = (-b - root) / (2 * a);
+	float z1 = p.z + d.z * t1;
+	float z2 = p.z + d.z * t2;
+	int k1 = 0, k2 = 0;   // 0 side, 1 top cap, 2 bottom cap, 3 invalid
+	if(z1 > 1) { if(z2 <= 1) { k1 = 1; t1 = (1 - p.z) / d.z; } else k1 = 3; }
+	else if(z1 < -1) { if(z2 >= -1) { k1 = 2; t1 = (-1 - p.z) / d.z; } else k1 = 3; }
+	if(z2 > 1) { if(z1 <= 1) { k2 = 1; t2 = (1 - p.z) / d.z; } else k2 = 3; }
+	else if(z2 < -1) { if(z1 >= -1) { k2 = 2; t2 = (-1 - p.z) / d.z; } else k2 = 3; }
+	if(k1 == 3 && k2 == 3) return -1;
+	if(t1 < 0 && t2 < 0) return -1;
+	float distance = tmin(t1, t2);
+	if(distance < 0) distance = tmax(t1, t2);
+	pos = p + d * distance;
+	int k = distance == t1 ? k1 : k2;
+	if(k == 0) {
+		if(pos.x == 0 && pos.y == 0) nrm = v3(1, 0, 0);
+		else nrm = normalise(v3(pos.x, pos.y, 0));
+	}
+	else if(k == 1) nrm = v3(0, 0, 1);
+	else nrm = v3(0, 0, -1);
+	return distance;
+}
+
+PT_DEV float hit_cone(V3 p, V3 d, V3& pos, V3& nrm) {
+	p.z -= 0.5f;
+	float a = d.x * d.x + d.y * d.y - d.z * d.z;
+	float b = 2 * p.x * d.x + 2 * p.y * d.y - 2 * p.z * d.z;
+	float c = p.x * p.x + p.y * p.y - p.z * p.z;
+	float disc = b * b - 4 * a * c;
+	if(disc < 0) return -1;
+	float root = sqrtf(disc);
+	float t1 = (-b + root) / (2 * a);
+	float t2 = (-b - root) / (2 * a);
+	float z1 = p.z + d.z * t1;
+	float z2 = p.z + d.z * t2;
+	int k1 = 0, k2 = 0;   // 0 side, 2 outside the cone's height
+	if(z1 > 0 || z1 < -1) k1 = 2;
+	if(z2 > 0 || z2 < -1) k2 = 2;
+	if(k1 == 2 && k2 == 2) return -1;
+	if(k1 == 2 || k2 == 2) {
+		if(k1 == 2) t1 = (-1 - p.z) / d.z;
+		else t2 = (-1 - p.z) / d.z;
+	}
+	if(t1 < 0 && t2 < 0) return -1;
+	float distance = tmin(t1, t2);
+	if(distance < 0) distance = tmax(t1, t2);
+	p.z += 0.5f;
+	pos = p + d * distance;
+	int k = distance == t1 ? k1 : k2;
+	if(k == 0) {
+		if(pos.x == 0 && pos.y == 0) {
+			nrm = v3(0, 0, 1);
+		} else {
+			V3 n = normalise(v3(pos.x, pos.y, 0));
+			nrm = normalise(v3(n.x, n.y, 1));
+		}
+	}
+	else nrm = v3(0, 0, -1);
+	return distance;
+}
+
+// Entity record loader: planes are addressed [plane*n + index].
+struct GeoRef {
+	const float4* base; int n; int i;
+	PT_DEV float4 plane(int p) const { return base[(size_t)p * (size_t)n + (size_t)i]; }
+};
+
+// transformToUnitSpace / transformToGlobalSpace (code/raycast.cpp:750-770)
+PT_DEV void to_unit(const GeoRef& g, V3 opos, bool rotated, V3 pos, V3 dir, V3& up, V3& ud) {
+	float4 si = g.plane(G_SCALEINV);
+	V3 sinv = v3(si.x, si.y, si.z);
+	pos = pos - opos;
+	if(rotated) {
+		float4 ri = g.plane(G_ROTINV);
+		pos = rotate(ri, pos);
+		dir = rotate(ri, dir);
+	}
+	up = pos * sinv;
+	ud = normalise(dir * sinv);
+}
+PT_DEV void to_world(const GeoRef& g, V3 opos, bool rotated, V3& pos, V3& nrm) {
+	float4 s = g.plane(G_SCALE), si = g.plane(G_SCALEINV);
+	pos = pos * v3(s.x, s.y, s.z);
+	nrm = nrm * v3(si.x, si.y, si.z);
+	if(rotated) {
+		float4 r = g.plane(G_ROT);
+		pos = rotate(r, pos);
+		nrm = rotate(r, nrm);
+	}
+	pos = pos + opos;
+	nrm = normalise(nrm);
+}
+
+// getIntersection (code/raycast.cpp:813-893).  p0 = plane G_POS already loaded by the caller.
+PT_DEV float intersect(const GeoRef& g, float4 p0, V3 rp, V3 rd, V3& pos, V3& nrm) {
+	float4 p3 = g.plane(G_DIM);
+	int tf = __float_as_int(p3.w);
+	int type = tf & 0xff;
+	bool rotated = (tf >> 8) & FLAG_ROTATED, even = (tf >> 8) & FLAG_EVEN;
+	V3 opos = v3(p0.x, p0.y, p0.z);
+	V3 dim = v3(p3.x, p3.y, p3.z);
+	float distance = -1;
+	if(type == PT_GEOM_SPHERE && even) {
+		distance = hit_sphere(rp, rd, opos, dim.x * 0.5f, pos, nrm);
+	} else if(type == PT_GEOM_BOX) {
+		if(!rotated) {
+			distance = hit_box(rp, rd, opos, dim, pos, nrm);
+		} else {
+			float4 ri = g.plane(G_ROTINV);
+			V3 lp = rp - opos;
+			V3 le = lp + rd;
+			lp = rotate(ri, lp);
+			le = rotate(ri, le);
+			V3 ld = normalise(le - lp);
+			distance = hit_box(lp, ld, v3(0, 0, 0), dim, pos, nrm);
+			if(distance != -1) {
+				float4 r = g.plane(G_ROT);
+				pos = rotate(r, pos);
+				pos = pos + opos;
+				nrm = rotate(r, nrm);
+				distance = length(rp - pos);
+			}
+		}
+	} else if(type <= PT_GEOM_CONE) {
+		V3 lp, ld;
+		to_unit(g, opos, rotated, rp, rd, lp, ld);
+		if(type == PT_GEOM_SPHERE) distance = hit_sphere(lp, ld, v3(0, 0, 0), 0.5f, pos, nrm);
+		else if(type == PT_GEOM_CYLINDER) distance = hit_cylinder(lp, ld, pos, nrm);
+		else distance = hit_cone(lp, ld, pos, nrm);
+		if(distance != -1) {
+			to_world(g, opos, rotated, pos, nrm);
+			distance = length(rp - pos);
+		}
+	}
+	return distance;
+}
+
+// ---- grid traversal (code/raycast.cpp:619-741) --------------------------------------------------
+struct Walk {
+	int cx, cy, cz;          // coord
+	int sx, sy, sz;          // step
+	float tx, ty, tz;        // tMax
+	float dx, dy, dz;        // tDelta
+	V3 lo, hi;               // current cell box
+};
+
+// Entry test of spatialGridTraverseInit: false when the ray never reaches the grid ("outside").
+// On success `p` is the point traversal starts from.
+PT_DEV bool grid_entry(const Grid& g, V3 rp, V3 rd, V3& p) {
+	V3 bmin = v3((float)(g.cmin[0] * g.cs[0]), (float)(g.cmin[1] * g.cs[1]), (float)(g.cmin[2] * g.cs[2]));
+	V3 bmax = v3((float)((g.cmin[0] + g.cnt[0]) * g.cs[0]), (float)((g.cmin[1] + g.cnt[1]) * g.cs[1]), (float)((g.cmin[2] + g.cnt[2]) * g.cs[2]));
+	p = rp;
+	if(!inside_box(rp, bmin, bmax)) {
+		V3 bdim = bmax - bmin;
+		V3 bpos = bmin + bdim / 2;
+		V3 ip, in;
+		float distance = hit_box(rp, rd, bpos, bdim, ip, in);
+		if(distance != -1) p = ip + rd * 0.0001f;
+		else return false;
+	}
+	return true;
+}
+
+PT_DEV int imin(int a, int b) { return a < b ? a : b; }
+PT_DEV int imax(int a, int b) { return a > b ? a : b; }
+
+#define PT_WALK_AXIS_INIT(A, P, D, CS, CMIN, CNT, C, S, T, DT) \
+	C = (int)(P / (float)CS) - CMIN; \
+	if(P < 0) C--; \
+	C = imin(imax(C, 0), CNT - 1); \
+	S = (D == 0) ? 0 : (D > 0 ? 1 : -1); \
+	{ int edge = (S == -1 ? C : C + 1) + CMIN; \
+	  T = (S != 0) ? ((float)(edge * CS) - P) / D : 3.402823466e+38f; } \
+	DT = (float)CS / D; \
+	if(DT < 0) DT = -DT;
+
+PT_DEV void walk_start(const Grid& g, V3 p, V3 d, Walk& w) {
+	PT_WALK_AXIS_INIT(x, p.x, d.x, g.cs[0], g.cmin[0], g.cnt[0], w.cx, w.sx, w.tx, w.dx)
+	PT_WALK_AXIS_INIT(y, p.y, d.y, g.cs[1], g.cmin[1], g.cnt[1], w.cy, w.sy, w.ty, w.dy)
+	PT_WALK_AXIS_INIT(z, p.z, d.z, g.cs[2], g.cmin[2], g.cnt[2], w.cz, w.sz, w.tz, w.dz)
+	w.lo = v3((float)((w.cx + g.cmin[0]) * g.cs[0]), (float)((w.cy + g.cmin[1]) * g.cs[1]), (float)((w.cz + g.cmin[2]) * g.cs[2]));
+	w.hi = v3((float)((w.cx + 1 + g.cmin[0]) * g.cs[0]), (float)((w.cy + 1 + g.cmin[1]) * g.cs[1]), (float)((w.cz + 1 + g.cmin[2]) * g.cs[2]));
+}
+
+#define PT_WALK_STEP(C, S, T, DT, CNT, CMIN, CS, LO, HI) \
+	{ C += S; \
+	  if(C < 0 || C >= CNT) return false; \
+	  T += DT; \
+	  if(S < 0) { HI = LO; LO = (float)((C + CMIN) * CS); } \
+	  else { LO = HI; HI = (float)((C + CMIN + 1) * CS); } }
+
+// spatialGridTraverseNext: the axis with the smallest tMax advances; ties go x<y ? (x<z ? X : Z) : (y<z ? Y : Z).
+PT_DEV bool walk_next(const Grid& g, Walk& w) {
+	if(w.tx < w.ty) {
+		if(w.tx < w.tz) PT_WALK_STEP(w.cx, w.sx, w.tx, w.dx, g.cnt[0], g.cmin[0], g.cs[0], w.lo.x, w.hi.x)
+		else PT_WALK_STEP(w.cz, w.sz, w.tz, w.dz, g.cnt[2], g.cmin[2], g.cs[2], w.lo.z, w.hi.z)
+	} else {
+		if(w.ty < w.tz) PT_WALK_STEP(w.cy, w.sy, w.ty, w.dy, g.cnt[1], g.cmin[1], g.cs[1], w.lo.y, w.hi.y)
+		else PT_WALK_STEP(w.cz, w.sz, w.tz, w.dz, g.cnt[2], g.cmin[2], g.cs[2], w.lo.z, w.hi.z)
+	}
+	return true;
+}
+
+#define PT_HASH_INIT 1469598103934665603ULL
+PT_DEV uint64_t hash_cell(uint64_t h, int index) { return (h ^ (uint64_t)(uint32_t)(index + 1)) * 1099511628211ULL; }
+
+// castRayAll (code/raycast.cpp:895-926): every entity, bounding-sphere prefilter first.  The
+// traverse-init the reference runs before it (code/raycast.cpp:1101) only matters for `outside`.
+PT_DEV int cast_all(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm) {
+	V3 entry;
+	if(!grid_entry(sc.grid, rp, rd, entry)) return 0;   // outside: only planes would be tested, and there are none
+	int id = 0;
+	float best = 3.402823466e+38f;
+	for(int i = 0; i < sc.n; i++) {
+		GeoRef g = { sc.geo, sc.n, i };
+		float4 p0 = g.plane(G_POS);
+		if(touches_sphere(rp, rd, v3(p0.x, p0.y, p0.z), p0.w)) {
+			V3 p, q;
+			float distance = intersect(g, p0, rp, rd, p, q);
+			if(distance > 0 && distance < best) {
+				best = distance;
+				id = i + 1;
+				hpos = p;
+				hnrm = q;
+			}
+		}
+	}
+	return id;
+}
+
+// castRay (code/raycast.cpp:928-986): walk the grid, accept a hit only inside the current cell,
+// stop at the first cell that produced one.  Items are in ascending id, so on equal distance the
+// lowest id wins, as in the reference.
+template <bool HASH>
+PT_DEV int cast_grid(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, uint64_t& hash) {
+	V3 start;
+	if(!grid_entry(sc.grid, rp, rd, start)) return 0;
+	Walk w;
+	walk_start(sc.grid, start, rd, w);
+	int id = 0;
+	float best = 3.402823466e+38f;
+	do {
+		int cell = w.cz * sc.grid.cnt[1] * sc.grid.cnt[0] + w.cy * sc.grid.cnt[0] + w.cx;
+		if(HASH) hash = hash_cell(hash, cell);
+		uint32_t k0 = sc.cell_start[cell], k1 = sc.cell_start[cell + 1];
+		for(uint32_t k = k0; k < k1; k++) {
+			int oi = (int)sc.cell_items[k];
+			GeoRef g = { sc.geo, sc.n, oi };
+			float4 p0 = g.plane(G_POS);
+			V3 p, q;
+			float distance = intersect(g, p0, rp, rd, p, q);
+			if(distance > 0 && distance < best && inside_box(p, w.lo, w.hi)) {
+				best = distance;
+				id = oi + 1;
+				hpos = p;
+				hnrm = q;
+			}
+		}
+		if(id != 0) break;
+	} while(walk_next(sc.grid, w));
+	return id;
+}
+
+template <bool HASH>
+PT_DEV int cast(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, uint64_t& hash) {
+	if(sc.brute) return cast_all(sc, rp, rd, hpos, hnrm);
+	return cast_grid<HASH>(sc, rp, rd, hpos, hnrm, hash);
+}
+
+// ---- optics (code/raycast.cpp:194-242) -----------------------------------------------------------
+// clamp(-1, 1, x) in the reference binds as clamp(value=-1, lo=1, hi=x) and evaluates to (1 > x ? x : 1).
+PT_DEV float cap_one(float x) { return 1.0f > x ? x : 1.0f; }
+PT_DEV V3 refract_dir(V3 incident, V3 normal, float ior) {
+	float cosi = cap_one(dot(incident, normal));
+	float etai = 1, etat = ior;
+	V3 n = normal;
+	if(cosi < 0) cosi = -cosi;
+	else { float t = etai; etai = etat; etat = t; n = -normal; }
+	float eta = etai / etat;
+	float k = 1 - eta * eta * (1 - cosi * cosi);
+	if(k < 0) return v3(0, 0, 0);
+	return incident * eta + n * (eta * cosi - sqrtf(k));
+}
+PT_DEV float fresnel(V3 incident, V3 normal, float ior) {
+	float cosi = cap_one(dot(incident, normal));
+	float etai = 1, etat = ior;
+	if(cosi > 0) { float t = etai; etai = etat; etat = t; }
+	float sint = etai / etat * sqrtf(tmax(0.0f, 1 - cosi * cosi));
+	if(sint >= 1) return 1;
+	float cost = sqrtf(tmax(0.0f, 1 - sint * sint));
+	cosi = fabsf(cosi);
+	float rs = ((etat * cosi) - (etai * cost)) / ((etat * cosi) + (etai * cost));
+	float rp = ((etai * cosi) - (etat * cost)) / ((etai * cosi) + (etat * cost));
+	return (rs * rs + rp * rp) / 2;
+}
+
+// ---- one bounce of shading (code/raycast.cpp:1109-1260) -----------------------------------------
+// Returns true when the path continues.  rp/rd are updated to the next ray.
+PT_DEV bool shade(const Scene& sc, const Frame& fr, int id, V3 hp, V3 hn, int bounce, V3& rp, V3& rd, V3& att, V3& col, Rng& rng) {
+	if(id != 0) {
+		float4 m0 = sc.mat[(size_t)M_COLOR * sc.n + (id - 1)];
+		float4 m1 = sc.mat[(size_t)M_EMIT * sc.n + (id - 1)];
+		V3 albedo = v3(m0.x, m0.y, m0.z), emit = v3(m1.x, m1.y, m1.z);
+		float refl = m0.w, ior = m1.w;
+		if(!is_zero(emit)) col = col + att * emit;
+		if(ior != 1.0f) {
+			float ratio = fresnel(rd, hn, ior);
+			V3 through = refract_dir(rd, hn, ior);
+			if(is_zero(through)) ratio = 1;
+			V3 bias = hn * 0.0001f;
+			bool outside = dot(rd, hn) < 0;
+			float u = (float)(int)rng_bounded<1000>(rng) * 0.001f;   // randomFloatPCG(0, 1, 0.001f): {0..999}/1000
+			if(u < ratio) {
+				rd = mirror(rd, hn);
+				rp = hp + (outside ? bias : -bias);
+			} else {
+				rd = through;
+				rp = hp + (outside ? -bias : bias);
+			}
+			att = att * albedo;
+		} else {
+			rp = hp + hn * 0.0001f;
+			V3 spec = v3(0, 0, 0), diff = v3(0, 0, 0);
+			if(refl != 0.0f) spec = mirror(rd, hn);
+			if(refl != 1.0f) {
+				float4 t = sc.dirs[rng_bounded<20000>(rng)];
+				diff = v3(t.x, t.y, t.z);
+				if(dot(diff, hn) < 0) diff = mirror(diff, hn);
+			}
+			V3 out = -rd;
+			V3 in = v3(blend(refl, diff.x, spec.x), blend(refl, diff.y, spec.y), blend(refl, diff.z, spec.z));
+			rd = in;                                     // not normalised when 0 < refl < 1, as in the reference
+			float cosine = blend(1 - refl, 1, dot(in, hn));
+			att = ((att * albedo) / 3.14159274101257324f) * cosine;
+			float rough = sc.geo[(size_t)G_SCALE * sc.n + (id - 1)].w;
+			if(rough != 0.0f) {                          // Oren-Nayar (code/raycast.cpp:1199-1221)
+				float r2 = rough * rough;
+				float a = 1 - 0.5f * (r2 / (r2 + 0.33f));
+				float b = 0.45f * (r2 / (r2 + 0.09f));
+				float cos_in = dot(rd, hn);
+				float cos_out = dot(out, hn);
+				V3 lp = normalise(rd - hn * cos_in);
+				V3 vp = normalise(out - hn * cos_out);
+				float cos_phi = dot(lp, vp);
+				float th_in = acosf(cos_in);
+				float th_out = acosf(cos_out);
+				float alpha = tmax(th_in, th_out);
+				float beta = tmin(th_in, th_out);
+				float orna = a + (b * tmax(0.0f, cos_phi) * sinf(alpha) * tanf(beta));
+				att = att * orna;
+			}
+		}
+		return !is_zero(att);
+	} else if(bounce == 0) {
+		col = col + fr.bg;
+		return false;
+	} else {
+		float ld = dot(rd, fr.light_dir);
+		ld = ld < 0 ? 0.0f : ld;
+		col = col + att * (fr.ambient + fr.light * ld);
+		return false;
+	}
+}
+
+// ---- camera (code/raycast.cpp:1040-1084) --------------------------------------------------------
+PT_DEV V3 pixel_origin(const Frame& fr, int x, int y) {
+	float px = (float)x / (float)fr.width, py = (float)y / (float)fr.height;
+	return (fr.top_left + fr.right_width * px) + fr.down_height * py;
+}
+PT_DEV void camera_ray(const Scene& sc, const Frame& fr, V3 origin, float2 s, int lens_index, V3& rp, V3& rd) {
+	rp = (origin + fr.right_px * s.x) + fr.down_px * s.y;
+	if(fr.aperture == 0.0f) {
+		rd = normalise(rp - fr.cam_pos);
+	} else {
+		V3 focal = v3(0, 0, 0);
+		V3 through = rp - fr.cam_pos;
+		V3 plane_pos = fr.cam_pos + fr.cam_dir * fr.focal_distance;
+		float a = dot(fr.back, through);                     // linePlaneIntersection, code/rt_math.cpp:2343-2359
+		if(a != 0) {
+			float distance = dot(fr.back, (plane_pos - rp)) / a;
+			if(distance >= 0) focal = rp + through * distance;
+		}
+		float2 lens = sc.disc[lens_index % 20000];
+		float ox = lens.x * fr.aperture;
+		float oy = lens.y * fr.aperture;
+		rp = rp + (fr.right * ox + fr.down * oy);
+		rd = normalise(focal - rp);
+	}
+}
+
+// Stream ids of the per-sample seed policy: one stream per pixel (lens table start) and one per
+// camera sample; `stride` bounds the samples a tile may hold.
+#define PT_STREAM_STRIDE 4096ULL
+PT_DEV int lens_start(const Frame& fr, int x, int y) {
+	Rng r;
+	rng_seed(r, fr.seed, (uint64_t)y * (uint64_t)fr.width + (uint64_t)x);
+	return (int)rng_bounded<20000>(r);
+}
+PT_DEV void sample_stream(const Frame& fr, int x, int y, int si, uint64_t pass, Rng& r) {
+	uint64_t wh = (uint64_t)fr.width * (uint64_t)fr.height;
+	uint64_t pix = (uint64_t)y * (uint64_t)fr.width + (uint64_t)x;
+	rng_seed(r, fr.seed + pass, wh + pix * PT_STREAM_STRIDE + (uint64_t)si);
+}
+
+}  // namespace ptd

@@ -1,0 +1,274 @@
+// HIP kernels of the render core (gfx950 / CDNA4, wave64) and their launchers.
+//
+// pt_k_trace is the whole per-pixel loop nest of the reference's tile job
+// (code/raycast.cpp:991-1289) as ONE persistent kernel organised as a wavefront state machine:
+// every lane owns one pixel at a time and carries one path; each trip of the wave's loop runs the
+// three stages  generate (camera ray of the next sample) -> extend (ray cast) -> shade  for the
+// lanes that need them.  A lane whose path ends regenerates the next sample of its pixel in the
+// same trip, and a lane whose pixel is finished pulls a new pixel from the wave's tile pool, so the
+// live rays stay compacted in the 64 lanes between bounces without ever going through memory.
+// Per-pixel sums are kept in registers in sample order, so the image is a pure function of the
+// inputs: independent of wave scheduling, grid size and GPU count.
+#include "pt_device.h"
+
+using namespace ptd;
+
+namespace {
+
+constexpr int kBlock = 256;            // 4 wavefronts; waves never synchronise with each other
+constexpr int kGroup = 64;             // pixels per pool refill = one 8x8 image tile
+
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ int lanes_below(uint64_t mask) {
+	return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Lane states of the trace loop.
+enum { NEED_PIXEL = 0, NEED_PATH = 1, IN_FLIGHT = 2, RETIRED = 3 };
+
+__global__ __launch_bounds__(kBlock) void pt_k_trace(ptl::TraceJob job) {
+	const Scene& sc = job.scene;
+	const Frame& fr = job.frame;
+	const int lane = lane_id();
+
+	// wave-uniform tile pool
+	int pool_next = 0, pool_end = 0;
+	bool dry = false;
+
+	// per-lane pixel state
+	int state = NEED_PIXEL;
+	int px = 0, py = 0, si = 0, si_end = 0, n_samples = 0, sample_base = 0, lens = 0;
+	size_t out_index = 0;
+	uint64_t pass = 0;
+	V3 origin = v3(0, 0, 0), sum = v3(0, 0, 0);
+	// per-lane path state
+	V3 rp = v3(0, 0, 0), rd = v3(0, 0, 1), att = v3(1, 1, 1), col = v3(0, 0, 0);
+	int bounce = 0;
+	Rng rng = { 0, 1 };
+	uint32_t casts = 0;
+
+	for(;;) {
+		// ---- stage 0: lanes without a pixel draw one from the wave's pool -------------------
+		uint64_t want = __ballot(state == NEED_PIXEL);
+		while(want != 0) {
+			if(pool_next == pool_end) {
+				if(dry) break;
+				uint32_t g = 0, stop = 0;
+				if(lane == 0) {
+					stop = *job.abort_flag;
+					g = atomicAdd(job.group_counter, 1u);
+				}
+				g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+				stop = (uint32_t)__builtin_amdgcn_readfirstlane((int)stop);
+				if(stop != 0 || g >= (uint32_t)job.n_groups) { dry = true; break; }
+				pool_next = (int)g * kGroup;
+				pool_end = pool_next + kGroup;
+			}
+			int avail = pool_end - pool_next;
+			int rank = lanes_below(want);
+			if(state == NEED_PIXEL && rank < avail) {
+				int slot = pool_next + rank;
+				int local_tile = slot / kGroup, j = slot % kGroup;
+				int tile = local_tile * job.part_count + job.part_index;
+				px = (tile % job.tiles_x) * 8 + (j & 7);
+				py = (tile / job.tiles_x) * 8 + (j >> 3);
+				if(px < fr.width && py < fr.height) {
+					out_index = job.compact ? (size_t)slot : (size_t)py * (size_t)fr.width + (size_t)px;
+					int t = (py % fr.tile_w) * fr.tile_w + (px % fr.tile_w);
+					sample_base = sc.offsets[t];
+					n_samples = sc.offsets[t + 1] - sample_base;
+					if(n_samples == 0) {
+						// a blue-noise tile without samples: the reference divides 0/0 here (code/raycast.cpp:1270)
+						float* o = job.fb + out_index * 3;
+						o[0] = 0; o[1] = 0; o[2] = 0;
+					} else {
+						if(job.frame_index < 0) { si = 0; si_end = n_samples; pass = 0; }
+						else { si = job.frame_index % n_samples; si_end = si + 1; pass = (uint64_t)(job.frame_index / n_samples); }
+						lens = fr.aperture != 0.0f ? lens_start(fr, px, py) : 0;
+						origin = pixel_origin(fr, px, py);
+						sum = v3(0, 0, 0);
+						state = NEED_PATH;
+					}
+				}
+				// pixels of an edge tile that fall outside the image are skipped: the lane asks again
+			}
+			int asked = __popcll(want);
+			pool_next += asked < avail ? asked : avail;
+			want = __ballot(state == NEED_PIXEL);
+		}
+		if(dry && state == NEED_PIXEL) state = RETIRED;
+		if(__ballot(state != RETIRED) == 0) break;
+
+		// ---- stage 1: generate the camera ray of the next sample (code/raycast.cpp:1059-1090) ---
+		if(state == NEED_PATH) {
+			float2 s = sc.samples[sample_base + si];
+			camera_ray(sc, fr, origin, s, lens + si, rp, rd);
+			sample_stream(fr, px, py, si, pass, rng);
+			att = v3(1, 1, 1);
+			col = v3(0, 0, 0);
+			bounce = 0;
+			state = IN_FLIGHT;
+		}
+
+		// ---- stage 2+3: extend one ray and shade the hit (code/raycast.cpp:1092-1261) ---------
+		if(state == IN_FLIGHT) {
+			V3 hp = v3(0, 0, 0), hn = v3(0, 0, 0);
+			uint64_t unused = 0;
+			int id = cast<false>(sc, rp, rd, hp, hn, unused);
+			casts++;
+			bool alive = shade(sc, fr, id, hp, hn, bounce, rp, rd, att, col, rng);
+			bounce++;
+			if(!alive || bounce >= fr.max_bounces) {
+				sum = sum + clamp_hi(col, 1.0f);            // per-sample clamp before averaging (code/raycast.cpp:1263)
+				si++;
+				state = NEED_PATH;
+				if(si == si_end) {
+					float* o = job.fb + out_index * 3;
+					if(job.frame_index < 0) {
+						V3 c = clamp_hi(sum / (float)n_samples, 1.0f);   // code/raycast.cpp:1270
+						o[0] = c.x; o[1] = c.y; o[2] = c.z;
+					} else {
+						float* a = job.accum + out_index * 3;
+						V3 t = sum;
+						if(job.frame_index > 0) t = v3(a[0] + sum.x, a[1] + sum.y, a[2] + sum.z);
+						a[0] = t.x; a[1] = t.y; a[2] = t.z;
+						V3 c = clamp_hi(t / (float)(job.frame_index + 1), 1.0f);
+						o[0] = c.x; o[1] = c.y; o[2] = c.z;
+					}
+					state = NEED_PIXEL;
+				}
+			}
+		}
+	}
+
+	// ray-cast count: one atomic per wave
+	if(job.stats) {
+		uint32_t total = casts;
+		for(int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
+		if(lane == 0) atomicAdd((unsigned long long*)job.stats, (unsigned long long)total);
+	}
+}
+
+// Debug pass: entity hit by, and grid cells visited by, the primary ray of camera sample 0 of
+// every pixel.  Same device functions as the trace kernel.
+__global__ __launch_bounds__(kBlock) void pt_k_primary(Scene sc, Frame fr, int32_t* hit_id, uint64_t* cell_hash) {
+	int i = blockIdx.x * kBlock + threadIdx.x;
+	if(i >= fr.width * fr.height) return;
+	int x = i % fr.width, y = i / fr.width;
+	int t = (y % fr.tile_w) * fr.tile_w + (x % fr.tile_w);
+	int base = sc.offsets[t];
+	int count = sc.offsets[t + 1] - base;
+	int id = -1;
+	uint64_t h = 0;
+	if(count > 0) {
+		V3 rp, rd, hp, hn;
+		int lens = fr.aperture != 0.0f ? lens_start(fr, x, y) : 0;
+		camera_ray(sc, fr, pixel_origin(fr, x, y), sc.samples[base], lens, rp, rd);
+		h = PT_HASH_INIT;
+		id = cast<true>(sc, rp, rd, hp, hn, h);
+		if(sc.brute) h = 0;
+	}
+	if(hit_id) hit_id[i] = id;
+	if(cell_hash) cell_hash[i] = h;
+}
+
+// One-ray queries (picking, focal-distance probe) and the intersection-level parity tests.
+__global__ __launch_bounds__(kBlock) void pt_k_cast(Scene sc, const float* origins, const float* dirs, int n,
+                                                    int32_t* hit_id, float* hit_pos, float* hit_nrm) {
+	int i = blockIdx.x * kBlock + threadIdx.x;
+	if(i >= n) return;
+	V3 rp = v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
+	V3 rd = v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
+	V3 hp = v3(0, 0, 0), hn = v3(0, 0, 0);
+	uint64_t unused = 0;
+	int id = cast<false>(sc, rp, rd, hp, hn, unused);
+	if(id == 0) { hp = v3(0, 0, 0); hn = v3(0, 0, 0); }
+	hit_id[i] = id;
+	if(hit_pos) { hit_pos[3 * i] = hp.x; hit_pos[3 * i + 1] = hp.y; hit_pos[3 * i + 2] = hp.z; }
+	if(hit_nrm) { hit_nrm[3 * i] = hn.x; hit_nrm[3 * i + 1] = hn.y; hit_nrm[3 * i + 2] = hn.z; }
+}
+
+// Screenshot encoding (code/app.cpp:1541-1547, code/rt_math.cpp:351-353,3634-3640).
+__global__ __launch_bounds__(kBlock) void pt_k_srgb8(const float* rgb, size_t n, uint8_t* out) {
+	size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+	if(i >= n) return;
+	float v = rgb[i];
+	if(v < 0.0031308f) v *= 12.92f;
+	else v = 1.055f * (float)pow((double)v, (double)(1.0f / 2.4f)) - 0.055f;
+	out[i] = (uint8_t)(int)roundf(v * 255);
+}
+
+// Multi-GPU: tile-major partition buffers -> row-major image (after the framebuffer gather).
+__global__ __launch_bounds__(kBlock) void pt_k_assemble(const float* parts, size_t stride, int part_count, int width, int height,
+                                                        int tiles_x, float* rgb) {
+	int i = blockIdx.x * kBlock + threadIdx.x;
+	if(i >= width * height) return;
+	int x = i % width, y = i / width;
+	int tile = (y >> 3) * tiles_x + (x >> 3);
+	int part = tile % part_count, local = tile / part_count;
+	const float* src = parts + (size_t)part * stride + ((size_t)local * kGroup + (size_t)((y & 7) * 8 + (x & 7))) * 3;
+	float* dst = rgb + (size_t)i * 3;
+	dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+}
+
+}  // namespace
+
+namespace ptl {
+
+const char* trace_kernel_name() { return "pt_k_trace"; }
+
+hipError_t launch_trace(const TraceJob& job, hipStream_t stream, int* grid_blocks_out) {
+	static int blocks_per_cu = 0, cus = 0;
+	if(blocks_per_cu == 0) {
+		int dev = 0;
+		hipError_t e = hipGetDevice(&dev);
+		if(e != hipSuccess) return e;
+		hipDeviceProp_t prop;
+		e = hipGetDeviceProperties(&prop, dev);
+		if(e != hipSuccess) return e;
+		cus = prop.multiProcessorCount;
+		int b = 0;
+		e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, pt_k_trace, kBlock, 0);
+		if(e != hipSuccess) return e;
+		blocks_per_cu = b > 0 ? b : 1;
+	}
+	hipError_t e = hipMemsetAsync(job.group_counter, 0, sizeof(uint32_t), stream);
+	if(e != hipSuccess) return e;
+	// persistent launch: every resident wave pulls 64-pixel tiles until the partition is drained
+	long waves_needed = job.n_groups;
+	long blocks = (waves_needed + 3) / 4;
+	long resident = (long)cus * blocks_per_cu;
+	if(blocks > resident) blocks = resident;
+	if(blocks < 1) blocks = 1;
+	if(grid_blocks_out) *grid_blocks_out = (int)blocks;
+	hipLaunchKernelGGL(pt_k_trace, dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
+	return hipGetLastError();
+}
+
+hipError_t launch_primary_aov(const SceneDev& sc, const FrameDev& fr, int32_t* hit_id, uint64_t* cell_hash, hipStream_t stream) {
+	int n = fr.width * fr.height;
+	hipLaunchKernelGGL(pt_k_primary, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, sc, fr, hit_id, cell_hash);
+	return hipGetLastError();
+}
+
+hipError_t launch_cast(const SceneDev& sc, const float* origins, const float* dirs, int n, int32_t* hit_id, float* hit_pos,
+                       float* hit_nrm, hipStream_t stream) {
+	if(n <= 0) return hipSuccess;
+	hipLaunchKernelGGL(pt_k_cast, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, sc, origins, dirs, n, hit_id, hit_pos, hit_nrm);
+	return hipGetLastError();
+}
+
+hipError_t launch_srgb8(const float* rgb, size_t n, uint8_t* out, hipStream_t stream) {
+	if(n == 0) return hipSuccess;
+	hipLaunchKernelGGL(pt_k_srgb8, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, rgb, n, out);
+	return hipGetLastError();
+}
+
+hipError_t launch_assemble(const float* parts, size_t stride, int part_count, int width, int height, float* rgb, hipStream_t stream) {
+	int n = width * height;
+	int tiles_x = (width + 7) / 8;
+	hipLaunchKernelGGL(pt_k_assemble, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, parts, stride, part_count, width, height, tiles_x, rgb);
+	return hipGetLastError();
+}
+
+}  // namespace ptl

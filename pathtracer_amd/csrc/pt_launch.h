@@ -1,0 +1,63 @@
+// Host-callable launchers of the device passes (implemented in pt_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptl {
+
+// Plain-data mirrors of the device-side Scene / Frame structs (pt_device.h) so that host code
+// does not need to include device code.
+struct Vec { float x, y, z; };
+
+struct GridDev { int cmin[3], cnt[3], cs[3]; };
+
+struct SceneDev {
+	const float4* geo;
+	const float4* mat;
+	const uint32_t* cell_start;
+	const uint32_t* cell_items;
+	const float4* dirs;
+	const float2* disc;
+	const float2* samples;
+	const int32_t* offsets;     // tile_w^2 + 1 sample offsets
+	int n;
+	int brute;
+	GridDev grid;
+};
+
+struct FrameDev {
+	Vec cam_pos, cam_dir, right, down, back, right_width, down_height, right_px, down_px, top_left;
+	Vec light_dir, bg, ambient, light;
+	float focal_distance, aperture;
+	int width, height, tile_w;
+	int max_bounces;
+	uint64_t seed;
+};
+
+// Pixels are handed to wavefronts in groups of 64 = one 8x8 image tile.  A context renders the
+// tiles t with t % part_count == part_index.
+struct TraceJob {
+	SceneDev scene;
+	FrameDev frame;
+	float* fb;                  // row-major image, or tile-major [local tile][64][3] when compact
+	float* accum;               // progressive accumulation buffer (same layout as fb), may be null
+	uint32_t* group_counter;    // device word, zeroed by the launcher
+	const volatile uint32_t* abort_flag;   // host-pinned word, non-zero = stop fetching tiles
+	uint64_t* stats;            // device: [0] ray casts
+	int tiles_x, tiles_y;
+	int n_groups;               // tiles owned by this partition
+	int part_index, part_count;
+	int frame_index;            // -1: every sample; >= 0: one sample, progressive
+	int compact;
+};
+
+hipError_t launch_trace(const TraceJob& job, hipStream_t stream, int* grid_blocks_out);
+hipError_t launch_primary_aov(const SceneDev& sc, const FrameDev& fr, int32_t* hit_id, uint64_t* cell_hash, hipStream_t stream);
+hipError_t launch_cast(const SceneDev& sc, const float* origins, const float* dirs, int n, int32_t* hit_id,
+                       float* hit_pos, float* hit_nrm, hipStream_t stream);
+hipError_t launch_srgb8(const float* rgb, size_t n, uint8_t* out, hipStream_t stream);
+// Tile-major partition buffers (part_count of them, each `stride` floats apart) -> row-major image.
+hipError_t launch_assemble(const float* parts, size_t stride, int part_count, int width, int height, float* rgb, hipStream_t stream);
+const char* trace_kernel_name();
+
+}  // namespace ptl

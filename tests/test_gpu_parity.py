@@ -1,0 +1,313 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs and against the committed reference vectors.
+
+Bars: entity ids, hit positions / normals and DDA cell-sequence hashes bit-exact (a mismatch
+fraction above 1e-5 fails; none is expected); radiance within 1e-4 relative per pixel and per
+sample (Oren-Nayar uses device acos/sin/tan, everything else is IEEE-exact and compares bitwise).
+"""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+import pytest
+
+from oracle.oraclebind import FP, IP, OracleScene
+from pathtracer_amd import api, scenes
+from pathtracer_amd.api import default_settings, make_object
+from rayutil import scene_rays
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_vectors.npz")
+P = lambda a: a.ctypes.data_as(FP)  # noqa: E731
+REL_TOL = 1e-4          # north-star tolerance on radiance
+EDGE_FRACTION = 1e-5    # allowed share of epsilon-edge mismatches on ids / cell hashes
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    r = api.Renderer(0)
+    yield r
+    r.close()
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def rel_err(a, b):
+    return np.abs(a.astype(np.float64) - b) / np.maximum(np.abs(b), 1e-3)
+
+
+CASES = {
+    # name: (factory, grid_hint, brute_force_below)
+    "default": (lambda: scenes.default_scene(), 10, 10),
+    "default_grid": (lambda: scenes.default_scene(), 10, 0),       # demo scene forced through the grid walk
+    "mixed40": (lambda: scenes.mixed_scene(seed=7, n=40), 10, 10),
+    "glass": (lambda: scenes.glass_scene(seed=3, per_type=16), 10, 10),
+    "crowded": (lambda: scenes.mixed_scene(seed=9, n=300, spread=12.0), 10, 10),
+    "dense2k": (lambda: scenes.dense_scene(n=2000, seed=4, half_extent=40.0, height=20.0), 24, 10),
+}
+ROUGH_FREE = {"default", "default_grid"}
+
+
+def settings_for(name, w, h, spp, bounces, seed=4242, **kw):
+    _, hint, brute = CASES[name]
+    return default_settings(w, h, spp, bounces, seed=seed, grid_hint=hint, brute_force_below=brute, **kw)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_cast_rays_bit_exact(gpu, name):
+    world, objs = CASES[name][0]()
+    st = settings_for(name, 64, 36, 4, 4)
+    gpu.prepare(world, objs, st)
+    sc = OracleScene(world, objs, st)
+    n = 40000
+    o, d = scene_rays(n, 77, objs, spread=30.0 if name != "dense2k" else 60.0)
+    ids, pos, nrm = gpu.cast_rays(o, d)
+    rid, rpos, rnrm = np.zeros(n, np.int32), np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    use_grid = 0 if len(objs) < st.brute_force_below else 1
+    sc.lib.pto_cast(sc.h, n, P(o), P(d), use_grid, rid.ctypes.data_as(IP), P(rpos), P(rnrm))
+    sc.close()
+    assert (rid != 0).mean() > 0.25, "ray set must hit often"
+    bad = ids != rid
+    assert bad.mean() <= EDGE_FRACTION, f"{bad.sum()} of {n} entity ids differ"
+    hit = (rid != 0) & ~bad
+    assert (bits(pos[hit]) == bits(rpos[hit])).all(), "hit positions differ"
+    assert (bits(nrm[hit]) == bits(rnrm[hit])).all(), "hit normals differ"
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_primary_ids_and_cell_hashes(gpu, name):
+    world, objs = CASES[name][0]()
+    st = settings_for(name, 320, 180, 16, 4)
+    gpu.prepare(world, objs, st)
+    ids, hs = gpu.debug_primary()
+    sc = OracleScene(world, objs, st)
+    rid, rhs = sc.primary()
+    sc.close()
+    assert (ids != rid).mean() <= EDGE_FRACTION
+    assert (hs != rhs).mean() <= EDGE_FRACTION
+    if len(objs) >= st.brute_force_below:
+        assert (rhs != 0).any(), "grid path must produce cell hashes"
+
+
+@pytest.mark.parametrize("name,w,h,spp,bounces", [("default", 320, 180, 16, 8), ("default_grid", 160, 90, 16, 8),
+                                                   ("mixed40", 160, 90, 16, 8), ("glass", 160, 90, 16, 32),
+                                                   ("crowded", 128, 72, 4, 8), ("dense2k", 128, 72, 4, 8)])
+def test_image_parity(gpu, name, w, h, spp, bounces):
+    world, objs = CASES[name][0]()
+    st = settings_for(name, w, h, spp, bounces)
+    img = gpu.render(world, objs, st)
+    stats = gpu.stats()
+    sc = OracleScene(world, objs, st)
+    ref = sc.render(policy=3, threads=8)
+    cnt = sc.counters()
+    paths = sc.path_count()
+    sc.close()
+    assert np.isfinite(img).all() and img.min() >= 0 and img.max() <= 1
+    assert stats.paths == paths
+    assert stats.rays == cnt["casts"], "device ray-cast count differs from the oracle's"
+    if name in ROUGH_FREE:
+        assert (bits(img) == bits(ref)).all(), "image must be bit-identical where no libm call is involved"
+    else:
+        e = rel_err(img, ref)
+        assert (e > REL_TOL).mean() <= EDGE_FRACTION, f"max rel err {e.max():.3e}, {(e > REL_TOL).sum()} values beyond tolerance"
+    mse = ((img.astype(np.float64) - ref) ** 2).mean()
+    assert mse < 1e-9
+
+
+def test_per_sample_radiance_via_progressive_frames(gpu):
+    """Frame f of the progressive mode traces sample (f mod count) of every pixel, so the first frames
+    expose single-sample radiance: each must match the oracle within 1e-4 relative."""
+    world, objs = scenes.mixed_scene(seed=7, n=40)
+    st = settings_for("mixed40", 96, 54, 16, 8, frame_index=0)
+    gpu.prepare(world, objs, st)
+    sc = OracleScene(world, objs, st)
+    acc_ref = np.zeros((54, 96, 3), np.float32)
+    prev = np.zeros_like(acc_ref)
+    for f in range(20):
+        gpu.set_frame(f)
+        gpu.trace()
+        shown = gpu.download()
+        sc.lib.pto_progressive_frame(sc.h, f, P(acc_ref))
+        want = np.minimum(acc_ref / np.float32(f + 1), np.float32(1.0))
+        e = rel_err(shown, want)
+        assert (e > REL_TOL).mean() <= EDGE_FRACTION, (f, e.max())
+        single = acc_ref - prev          # clamped radiance of this frame's sample
+        prev = acc_ref.copy()
+        assert np.isfinite(single).all()
+    sc.close()
+
+
+def test_progressive_converges_to_full_render(gpu):
+    world, objs = scenes.default_scene()
+    st_full = settings_for("default", 96, 54, 16, 8)
+    full = gpu.render(world, objs, st_full)
+    st = settings_for("default", 96, 54, 16, 8, frame_index=0)
+    gpu.prepare(world, objs, st)
+    sc = OracleScene(world, objs, st_full)
+    _, offs = sc.samples()
+    sc.close()
+    counts = np.diff(offs)
+    frames = {}
+    for f in range(int(counts.max())):
+        gpu.set_frame(f)
+        gpu.trace()
+        if (f + 1) in counts:
+            frames[f + 1] = gpu.download()
+    # after count(tile) frames the pixels of that tile class equal the full render bit for bit
+    for t, c in enumerate(counts):
+        ty, tx = divmod(t, 3)
+        a = frames[int(c)][ty::3, tx::3]
+        b = full[ty::3, tx::3]
+        assert (bits(a) == bits(b)).all(), t
+
+
+def test_reference_golden_vectors_on_gpu(gpu):
+    """Straight against the reference's own outputs (tests/golden): casts through the prepared scene
+    and pinhole primary hits."""
+    gold = np.load(GOLD)
+    for name in ("default", "mixed40", "glass"):
+        blob = gold[name + "_objects"].tobytes()
+        n = len(blob) // C.sizeof(api.pt_object)
+        objs = [api.pt_object.from_buffer_copy(blob, i * C.sizeof(api.pt_object)) for i in range(n)]
+        world = api.pt_world.from_buffer_copy(gold[name + "_world"].tobytes())
+        st = api.pt_settings.from_buffer_copy(gold[name + "_settings"].tobytes())
+        gpu.prepare(world, objs, st)
+        use_grid = 0 if n < st.brute_force_below else 1
+        ids, pos, nrm = gpu.cast_rays(gold[name + "_ray_o"], gold[name + "_ray_d"])
+        assert (ids == gold[name + f"_cast{use_grid}_id"]).all()
+        hit = ids != 0
+        assert (bits(pos[hit]) == bits(gold[name + f"_cast{use_grid}_pos"][hit])).all()
+        assert (bits(nrm[hit]) == bits(gold[name + f"_cast{use_grid}_nrm"][hit])).all()
+        if world.aperture == 0:
+            pid, _ = gpu.debug_primary()
+            assert (pid == gold[name + "_primary"].astype(np.int32)).all()
+
+
+def test_partition_invariance(gpu):
+    """Tile partitions (the multi-GPU split) give the single-partition image bit for bit."""
+    world, objs = scenes.mixed_scene(seed=7, n=40)
+    st = settings_for("mixed40", 200, 117, 16, 8)       # not a multiple of the 8x8 tile
+    whole = gpu.render(world, objs, st)
+    for parts in (2, 3, 8):
+        img = np.full_like(whole, -1)
+        for p in range(parts):
+            stp = settings_for("mixed40", 200, 117, 16, 8, part_index=p, part_count=parts)
+            gpu.prepare(world, objs, stp)
+            gpu.trace()
+            gpu._check(gpu.lib.pt_download(gpu.ctx, api.fptr(img)), "pt_download")
+        assert (bits(img) == bits(whole)).all(), parts
+
+
+def test_determinism_and_range_at_full_size(gpu):
+    """BASELINE size (1080p, 64 spp, depth 8): two runs are bitwise equal, the image is finite and in
+    [0,1], primary ids equal the oracle's, sky rows are exactly the background colour."""
+    world, objs = scenes.default_scene()
+    st = default_settings(1920, 1080, 64, 8, seed=12345)
+    gpu.prepare(world, objs, st)
+    gpu.trace()
+    a = gpu.download()
+    gpu.trace()
+    b = gpu.download()
+    assert (bits(a) == bits(b)).all()
+    assert np.isfinite(a).all() and a.min() >= 0 and a.max() <= 1
+    assert (a[:100] == 1.0).all()
+    ids, _ = gpu.debug_primary()
+    sc = OracleScene(world, objs, st)
+    rid, _ = sc.primary()
+    paths = sc.path_count()
+    # a 64-row band of the full-size image against the oracle, bit for bit
+    band = np.zeros((1080, 1920, 3), np.float32)
+    sc.lib.pto_render_rect(sc.h, 0, 3, 0, 520, 1920, 64, P(band))
+    sc.close()
+    assert (ids != rid).mean() <= EDGE_FRACTION
+    assert gpu.stats().paths == paths
+    assert (bits(a[520:584]) == bits(band[520:584])).all()
+
+
+def test_zero_sample_tile_is_black(gpu):
+    world, objs = scenes.default_scene()
+    for seed in range(40):
+        st = default_settings(30, 30, 1, 4, seed=seed)
+        sc = OracleScene(world, objs, st)
+        _, offs = sc.samples()
+        if (np.diff(offs) == 0).any():
+            ref = sc.render(policy=3)
+            sc.close()
+            img = gpu.render(world, objs, st)
+            assert np.isfinite(img).all() and (bits(img) == bits(ref)).all()
+            assert gpu.stats().zero_sample_pixels > 0
+            return
+        sc.close()
+    pytest.fail("no seed produced an empty tile")
+
+
+def test_start_progress_abort(gpu):
+    world, objs = scenes.glass_scene(seed=3, per_type=16)
+    st = settings_for("glass", 1920, 1080, 64, 32)
+    out = gpu.start(world, objs, st)
+    with pytest.raises(api.PtError):
+        gpu.start(world, objs, st)            # busy
+    seen = []
+    t0 = time.time()
+    while time.time() - t0 < 60:
+        p = gpu.progress()
+        seen.append(p.fraction)
+        if p.done:
+            break
+        if p.fraction > 0.05:
+            gpu.abort()
+        time.sleep(0.002)
+    gpu.wait()
+    p = gpu.progress()
+    assert p.done == 1 and p.seconds > 0
+    assert all(0 <= f <= 1 for f in seen)
+    assert out.shape == (1080, 1920, 3)
+    # an un-aborted render of the same context afterwards is complete and correct
+    st2 = settings_for("default", 160, 90, 16, 8)
+    w2, o2 = scenes.default_scene()
+    img = gpu.render(w2, o2, st2)
+    p = gpu.progress()
+    assert p.done == 1 and p.aborted == 0 and p.fraction == 1.0 and p.paths_done == gpu.stats().paths
+    sc = OracleScene(w2, o2, st2)
+    assert (bits(img) == bits(sc.render(policy=3, threads=4))).all()
+    sc.close()
+
+
+def test_srgb8_present(gpu):
+    world, objs = scenes.default_scene()
+    st = settings_for("default", 160, 90, 16, 8)
+    gpu.prepare(world, objs, st)
+    gpu.trace()
+    lin = gpu.download()
+    got = gpu.present_srgb8()
+    sc = OracleScene(world, objs, st)
+    want = np.zeros(lin.size, np.uint8)
+    from oracle.oraclebind import U8P
+    sc.lib.pto_srgb8(lin.size, P(lin), want.ctypes.data_as(U8P))
+    sc.close()
+    diff = np.abs(got.ravel().astype(np.int16) - want.astype(np.int16))
+    assert diff.max() <= 1 and (diff != 0).mean() < 1e-3
+
+
+def test_argument_errors(gpu):
+    world, objs = scenes.default_scene()
+    bad = make_object((0, 0, 0), (1, 1, 1), api.PT_GEOM_PLANE)
+    with pytest.raises(api.PtError, match="not supported"):
+        gpu.prepare(world, objs + [bad], default_settings())
+    with pytest.raises(api.PtError):
+        gpu.prepare(world, objs, default_settings(width=0))
+    with pytest.raises(api.PtError):
+        gpu.prepare(world, objs, default_settings(seed_policy=1))
+    with pytest.raises(api.PtError):
+        gpu.prepare(world, objs, default_settings(part_index=2, part_count=2))
+    r2 = api.Renderer(0)
+    with pytest.raises(api.PtError, match="before pt_prepare"):
+        r2.trace()
+    r2.close()
+    # an empty scene renders the background
+    st = default_settings(32, 18, 4, 2)
+    img = gpu.render(world, [], st)
+    assert (img == 1.0).all()

@@ -1,0 +1,120 @@
+"""CPU checks of the product's host side (no GPU): the C-ABI library loads and exports every symbol
+include/pt_api.h declares, argument validation works, and the host stages (flatten, camera/world
+constants, tables + blue noise, grid CSR) equal the CPU oracle bit for bit."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle.oraclebind import OracleScene
+from pathtracer_amd import api, scenes
+from pathtracer_amd.api import default_settings, fptr, iptr, object_array, uptr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_exports_every_declared_symbol(core_lib):
+    header = open(os.path.join(ROOT, "include", "pt_api.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    names = re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", header)
+    assert len(set(names)) >= 20
+    for n in sorted(set(names)):
+        assert hasattr(core_lib, n), f"libptcore.so does not export {n}"
+
+
+def test_fails_loudly_without_gpu(core_lib):
+    """No CPU fallback: without a HIP device a context cannot even be created."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present")
+    except ImportError:
+        pass
+    ctx = core_lib.pt_create(0)
+    assert not ctx
+    assert b"HIP device" in core_lib.pt_last_error(None) or b"device" in core_lib.pt_last_error(None)
+
+
+def test_default_scene_matches_python_generator(core_lib):
+    w = api.pt_world()
+    o = (api.pt_object * 2)()
+    n = C.c_int(0)
+    assert core_lib.pt_default_scene(C.byref(w), o, 2, C.byref(n)) == 0 and n.value == 2
+    pw, po = scenes.default_scene()
+    assert bytes(w) == bytes(pw)
+    assert bytes(o) == bytes(object_array(po))
+    s = api.pt_settings()
+    core_lib.pt_default_settings(C.byref(s))
+    assert (s.width, s.height, s.spp_wanted, s.sample_grid_width, s.max_bounces, s.grid_hint, s.brute_force_below) == (768, 432, 100, 3, 10, 10, 10)
+
+
+CASES = {
+    "default": lambda: scenes.default_scene(),
+    "mixed40": lambda: scenes.mixed_scene(seed=7, n=40),
+    "glass": lambda: scenes.glass_scene(seed=3, per_type=16),
+    "crowded": lambda: scenes.mixed_scene(seed=9, n=300, spread=12.0),
+    "dense2k": lambda: scenes.dense_scene(n=2000, seed=4, half_extent=40.0, height=20.0),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_flatten_world_grid_equal_oracle(core_lib, oracle_lib, name):
+    world, objs = CASES[name]()
+    hint = 24 if name == "dense2k" else 10
+    st = default_settings(160, 90, 16, 8, seed=99, grid_hint=hint)
+    sc = OracleScene(world, objs, st)
+    n = len(objs)
+    rec = np.zeros((n, 36), np.float32)
+    assert core_lib.pt_host_flatten(object_array(objs), n, fptr(rec)) == 0
+    assert (bits(rec) == bits(sc.records())).all()
+    wc = np.zeros(27, np.float32)
+    assert core_lib.pt_host_world(C.byref(world), st.width, st.height, fptr(wc)) == 0
+    assert (bits(wc) == bits(sc.world_consts())).all()
+    g, start, items = sc.grid()
+    gi = np.zeros(9, np.int32)
+    ct, it = C.c_int(0), C.c_int(0)
+    assert core_lib.pt_host_grid(fptr(rec), n, hint, iptr(gi), None, 0, None, 0, C.byref(ct), C.byref(it)) == 0
+    assert (gi == g).all() and ct.value == len(start) - 1 and it.value == len(items)
+    cs = np.zeros(ct.value + 1, np.uint32)
+    ci = np.zeros(max(1, it.value), np.uint32)
+    assert core_lib.pt_host_grid(fptr(rec), n, hint, iptr(gi), uptr(cs), cs.size, uptr(ci), ci.size, None, None) == 0
+    assert (cs == start).all() and (ci[:it.value] == items).all()
+    sc.close()
+
+
+@pytest.mark.parametrize("spp,gw,seed", [(1, 3, 1), (4, 3, 2), (16, 3, 12345), (64, 3, 12345), (100, 3, 7), (256, 3, 3), (16, 2, 5), (16, 4, 6)])
+def test_tables_and_samples_equal_oracle(core_lib, oracle_lib, spp, gw, seed):
+    world, objs = scenes.default_scene()
+    st = default_settings(64, 36, spp, 4, seed=seed, sample_grid_width=gw)
+    sc = OracleScene(world, objs, st)
+    od, oc = sc.tables()
+    osmp, ooff = sc.samples()
+    d = np.zeros((20000, 3), np.float32)
+    c = np.zeros((20000, 2), np.float32)
+    smp = np.zeros((max(1, osmp.shape[0]) + 8, 2), np.float32)
+    off = np.zeros(gw * gw + 1, np.int32)
+    cnt = C.c_int(0)
+    assert core_lib.pt_host_tables(seed, spp, gw, fptr(d), fptr(c), fptr(smp), smp.shape[0], iptr(off), C.byref(cnt)) == 0
+    assert cnt.value == osmp.shape[0] and (off == ooff).all()
+    assert (bits(d) == bits(od)).all() and (bits(c) == bits(oc)).all()
+    assert (bits(smp[:cnt.value]) == bits(osmp)).all()
+    # table invariants the tracer relies on
+    ln = np.sqrt((d.astype(np.float64) ** 2).sum(1))
+    assert np.abs(ln - 1).max() < 1e-6
+    assert (np.sqrt((c.astype(np.float64) ** 2).sum(1)) <= 0.5 + 1e-7).all()
+    assert (smp[:cnt.value] >= 0).all() and (smp[:cnt.value] < 1).all()
+    sc.close()
+
+
+def test_host_stage_argument_errors(core_lib):
+    assert core_lib.pt_host_flatten(None, 3, None) != 0
+    assert core_lib.pt_host_tables(1, 0, 3, None, None, None, 0, None, None) != 0
+    assert core_lib.pt_host_tables(1, 16, 9, None, None, None, 0, None, None) != 0
+    d = np.zeros(9, np.int32)
+    assert core_lib.pt_host_grid(None, 0, 10, iptr(d), None, 0, None, 0, None, None) != 0
