@@ -116,8 +116,8 @@ def cpu_baseline(world, objs, kw, budget_paths=160e6):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="demo-1080p-64spp-d8")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
@@ -208,7 +208,8 @@ def main():
                        "seed_policy": "per-sample PCG32 streams"},
         }
         roof = {"bound": "valu", "kernel": "pt_k_trace", "achieved": None, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                "frac": None, "traffic": None, "kernel_ms": kernel_ms}
+                "frac": None, "traffic": None, "kernel_ms": kernel_ms,
+                "kernel_ms_min": float(kstats.trace_ms_min), "kernel_ms_max": float(kstats.trace_ms_max)}
         if not args.no_cpu:
             base, counters, base_paths = cpu_baseline(world, objs, kw)
             out["cpu_baseline"] = base

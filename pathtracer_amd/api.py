@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CORE_PATH = os.path.join(ROOT, "pathtracer_amd", "libptcore.so")
+# PT_CORE_LIB selects another build of the same library (A/B timing of kernel variants)
+CORE_PATH = os.environ.get("PT_CORE_LIB") or os.path.join(ROOT, "pathtracer_amd", "libptcore.so")
 _libs = {}
 
 
@@ -64,7 +65,8 @@ class pt_stats(C.Structure):
                 ("zero_sample_pixels", C.c_uint64), ("samples_total", C.c_int32),
                 ("objects", C.c_int32), ("cells", C.c_int32 * 3), ("cell_size", C.c_int32 * 3),
                 ("cell_items", C.c_int32), ("bounce_passes", C.c_int32), ("trace_ms", C.c_float),
-                ("dominant_kernel_ms", C.c_float), ("prepare_ms", C.c_float)]
+                ("dominant_kernel_ms", C.c_float), ("prepare_ms", C.c_float),
+                ("trace_ms_min", C.c_float), ("trace_ms_max", C.c_float), ("trace_launches", C.c_int32)]
 
 
 def default_settings(width=64, height=36, spp=16, bounces=8, seed=12345, **kw):

@@ -54,7 +54,7 @@ struct pt_ctx {
 	bool prepared = false;
 
 	// device-resident scene
-	DevBuf geo, mat, cell_start, cell_items, dirs, disc, samples, offsets, fb, accum, counter, stats_dev, scratch;
+	DevBuf geo, mat, cell_start, cell_items, dirs, disc, samples, offsets, frame_dev, fb, accum, counter, stats_dev, scratch;
 	uint32_t* abort_flag = nullptr;      // host-pinned, read by the trace kernel
 	uint32_t* abort_flag_dev = nullptr;  // the same word as the device addresses it
 	uint32_t* counter_host = nullptr;    // host-pinned landing word for progress polls
@@ -215,7 +215,7 @@ int prepare(pt_ctx* c) {
 	for(int k = 0; k < 3; k++) { j.scene.grid.cmin[k] = gd.coord_min[k]; j.scene.grid.cnt[k] = gd.cell_count[k]; j.scene.grid.cs[k] = gd.cell_size[k]; }
 
 	// per-job constants of the tile job (code/raycast.cpp:1010-1021), evaluated once on the host
-	ptl::FrameDev& f = j.frame;
+	ptl::FrameDev f{};
 	auto mul = [](pt::f3 a, float b) { return pt::f3{ a.x * b, a.y * b, a.z * b }; };
 	pt::f3 down = { -wc.cam_up.x, -wc.cam_up.y, -wc.cam_up.z };
 	pt::f3 back = { -wc.cam_dir.x, -wc.cam_dir.y, -wc.cam_dir.z };
@@ -234,6 +234,8 @@ int prepare(pt_ctx* c) {
 	f.width = s.width; f.height = s.height; f.tile_w = s.sample_grid_width;
 	f.max_bounces = s.max_bounces;
 	f.seed = s.seed;
+	if((rc = upload(c, c->frame_dev, &f, sizeof f))) return rc;
+	j.frame = c->frame_dev.as<ptl::FrameDev>();
 
 	j.fb = c->fb.as<float>();
 	j.accum = s.frame_index >= 0 ? c->accum.as<float>() : nullptr;
@@ -300,11 +302,14 @@ int collect(pt_ctx* c) {
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> pend;
 	{ std::lock_guard<std::mutex> l(c->mu); pend.swap(c->pending); }
 	double sum = 0;
+	float lo = 3.4e38f, hi = 0;
 	for(auto& p : pend) {
 		float ms = 0;
 		PT_HIP(c, hipEventSynchronize(p.second));
 		PT_HIP(c, hipEventElapsedTime(&ms, p.first, p.second));
 		sum += ms;
+		lo = ms < lo ? ms : lo;
+		hi = ms > hi ? ms : hi;
 		c->event_pool.push_back(p.first);
 		c->event_pool.push_back(p.second);
 	}
@@ -313,6 +318,7 @@ int collect(pt_ctx* c) {
 		c->kernel_launches = (int)pend.size();
 		c->stats.trace_ms = (float)(sum / pend.size());
 		c->stats.dominant_kernel_ms = c->stats.trace_ms;
+		c->stats.trace_ms_min = lo; c->stats.trace_ms_max = hi; c->stats.trace_launches = (int)pend.size();
 		uint64_t rays = 0;
 		PT_HIP(c, hipMemcpy(&rays, c->stats_dev.p, sizeof rays, hipMemcpyDeviceToHost));
 		c->stats.rays = rays / (uint64_t)pend.size();
@@ -391,7 +397,7 @@ void pt_destroy(pt_ctx* c) {
 	if(c->active.load()) { *c->abort_flag = 1; join_worker(c); }
 	(void)hipSetDevice(c->device);
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
-	for(DevBuf* b : { &c->geo, &c->mat, &c->cell_start, &c->cell_items, &c->dirs, &c->disc, &c->samples, &c->offsets, &c->fb, &c->accum, &c->counter, &c->stats_dev, &c->scratch }) b->release();
+	for(DevBuf* b : { &c->geo, &c->mat, &c->cell_start, &c->cell_items, &c->dirs, &c->disc, &c->samples, &c->offsets, &c->frame_dev, &c->fb, &c->accum, &c->counter, &c->stats_dev, &c->scratch }) b->release();
 	for(auto& p : c->pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
 	for(hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
 	if(c->abort_flag) (void)hipHostFree(c->abort_flag);
@@ -565,7 +571,7 @@ int pt_debug_primary(pt_ctx* c, int32_t* hit_id, uint64_t* cell_hash) {
 	PT_HIP(c, c->scratch.reserve(hash_at + n * 8));
 	int32_t* d_id = c->scratch.as<int32_t>();
 	uint64_t* d_hash = (uint64_t*)((char*)c->scratch.p + hash_at);
-	PT_HIP(c, ptl::launch_primary_aov(c->job.scene, c->job.frame, d_id, d_hash, c->stream));
+	PT_HIP(c, ptl::launch_primary_aov(c->job.scene, c->job.frame, c->st.width, c->st.height, d_id, d_hash, c->stream));
 	PT_HIP(c, hipStreamSynchronize(c->stream));
 	if(hit_id) PT_HIP(c, hipMemcpy(hit_id, d_id, n * 4, hipMemcpyDeviceToHost));
 	if(cell_hash) PT_HIP(c, hipMemcpy(cell_hash, d_hash, n * 8, hipMemcpyDeviceToHost));

@@ -15,11 +15,40 @@ namespace ptd {
 
 #define PT_DEV __device__ __forceinline__
 
+// Read-only scene data is addressed through the constant address space: a load whose address is
+// wave-uniform (the brute-force loop over entities, the per-frame constants) then becomes a scalar
+// load into SGPRs instead of 64 identical vector loads; divergent addresses still use vector loads.
+#define PT_CONST __attribute__((address_space(4)))
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef const PT_CONST v4f* cf4;
+typedef const PT_CONST v2f* cf2;
+typedef const PT_CONST uint32_t* cu32;
+typedef const PT_CONST int32_t* ci32;
+
 using V3 = ptl::Vec;
-using Scene = ptl::SceneDev;
-using Frame = ptl::FrameDev;
 using Grid = ptl::GridDev;
+typedef const PT_CONST ptl::FrameDev* FrameRef;
+
+struct Scene {
+	cf4 geo, mat, dirs;
+	cf2 disc, samples;
+	cu32 cell_start, cell_items;
+	ci32 offsets;
+	int n, brute;
+	Grid grid;
+};
+__device__ __forceinline__ Scene scene_view(const ptl::SceneDev& d) {
+	Scene s;
+	s.geo = (cf4)d.geo; s.mat = (cf4)d.mat; s.dirs = (cf4)d.dirs;
+	s.disc = (cf2)d.disc; s.samples = (cf2)d.samples;
+	s.cell_start = (cu32)d.cell_start; s.cell_items = (cu32)d.cell_items;
+	s.offsets = (ci32)d.offsets;
+	s.n = d.n; s.brute = d.brute; s.grid = d.grid;
+	return s;
+}
 PT_DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_DEV V3 ld3(const PT_CONST V3& v) { return v3(v.x, v.y, v.z); }
 PT_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
 PT_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
 PT_DEV V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
@@ -48,7 +77,7 @@ PT_DEV V3 mirror(V3 dir, V3 n) {                            // reflectVector, co
 PT_DEV bool inside_box(V3 p, V3 lo, V3 hi) {                // pointInBox, inclusive (code/rt_math.cpp:3340-3349)
 	return p.x >= lo.x && p.x <= hi.x && p.y >= lo.y && p.y <= hi.y && p.z >= lo.z && p.z <= hi.z;
 }
-PT_DEV V3 rotate(float4 q /* w,x,y,z */, V3 v) {            // Quat*Vec3, code/rt_math.cpp:2902-2907
+PT_DEV V3 rotate(v4f q /* w,x,y,z */, V3 v) {            // Quat*Vec3, code/rt_math.cpp:2902-2907
 	V3 u = v3(q.y, q.z, q.w);
 	V3 c = cross(u, v);
 	V3 t = v3(c.x * 2, c.y * 2, c.z * 2);
@@ -81,7 +110,7 @@ PT_DEV uint32_t rng_bounded(Rng& r) {
 }
 
 // ---- scene as the kernels see it ----------------------------------------------------------------
-// Entities are flattened into structure-of-arrays planes of float4, split by use: six geometry
+// Entities are flattened into structure-of-arrays planes of v4f, split by use: six geometry
 // planes read while intersecting and two material planes read once per hit.
 //   G0 pos.xyz | bounding-sphere radius     G1 rot (w,x,y,z)          G2 rotInverse (w,x,y,z)
 //   G3 dim.xyz | type + flags<<8 (int bits) G4 dimScale.xyz | roughness   G5 dimScaleInverse.xyz | -
@@ -89,7 +118,8 @@ PT_DEV uint32_t rng_bounded(Rng& r) {
 enum { G_POS = 0, G_ROT = 1, G_ROTINV = 2, G_DIM = 3, G_SCALE = 4, G_SCALEINV = 5, G_PLANES = 6, M_COLOR = 0, M_EMIT = 1, M_PLANES = 2 };
 enum { FLAG_ROTATED = 1, FLAG_EVEN = 2 };
 
-struct Hit { int id; V3 pos, nrm; };
+// Material of the entity a ray hit: colorLinear|reflectionMod, emitColorLinear|refractiveIndex, roughness.
+struct Surface { v4f m0, m1; float rough; };
 
 // ---- analytic intersectors (code/raycast.cpp:390-585) -------------------------------------------
 PT_DEV float hit_sphere(V3 lp, V3 ld, V3 sp, float sr, V3& pos, V3& nrm) {
@@ -221,17 +251,17 @@ PT_DEV float hit_cone(V3 p, V3 d, V3& pos, V3& nrm) {
 
 // Entity record loader: planes are addressed [plane*n + index].
 struct GeoRef {
-	const float4* base; int n; int i;
-	PT_DEV float4 plane(int p) const { return base[(size_t)p * (size_t)n + (size_t)i]; }
+	cf4 base; int n; int i;
+	PT_DEV v4f plane(int p) const { return base[(size_t)p * (size_t)n + (size_t)i]; }
 };
 
 // transformToUnitSpace / transformToGlobalSpace (code/raycast.cpp:750-770)
 PT_DEV void to_unit(const GeoRef& g, V3 opos, bool rotated, V3 pos, V3 dir, V3& up, V3& ud) {
-	float4 si = g.plane(G_SCALEINV);
+	v4f si = g.plane(G_SCALEINV);
 	V3 sinv = v3(si.x, si.y, si.z);
 	pos = pos - opos;
 	if(rotated) {
-		float4 ri = g.plane(G_ROTINV);
+		v4f ri = g.plane(G_ROTINV);
 		pos = rotate(ri, pos);
 		dir = rotate(ri, dir);
 	}
@@ -239,11 +269,11 @@ PT_DEV void to_unit(const GeoRef& g, V3 opos, bool rotated, V3 pos, V3 dir, V3& 
 	ud = normalise(dir * sinv);
 }
 PT_DEV void to_world(const GeoRef& g, V3 opos, bool rotated, V3& pos, V3& nrm) {
-	float4 s = g.plane(G_SCALE), si = g.plane(G_SCALEINV);
+	v4f s = g.plane(G_SCALE), si = g.plane(G_SCALEINV);
 	pos = pos * v3(s.x, s.y, s.z);
 	nrm = nrm * v3(si.x, si.y, si.z);
 	if(rotated) {
-		float4 r = g.plane(G_ROT);
+		v4f r = g.plane(G_ROT);
 		pos = rotate(r, pos);
 		nrm = rotate(r, nrm);
 	}
@@ -252,8 +282,8 @@ PT_DEV void to_world(const GeoRef& g, V3 opos, bool rotated, V3& pos, V3& nrm) {
 }
 
 // getIntersection (code/raycast.cpp:813-893).  p0 = plane G_POS already loaded by the caller.
-PT_DEV float intersect(const GeoRef& g, float4 p0, V3 rp, V3 rd, V3& pos, V3& nrm) {
-	float4 p3 = g.plane(G_DIM);
+PT_DEV float intersect(const GeoRef& g, v4f p0, V3 rp, V3 rd, V3& pos, V3& nrm) {
+	v4f p3 = g.plane(G_DIM);
 	int tf = __float_as_int(p3.w);
 	int type = tf & 0xff;
 	bool rotated = (tf >> 8) & FLAG_ROTATED, even = (tf >> 8) & FLAG_EVEN;
@@ -266,7 +296,7 @@ PT_DEV float intersect(const GeoRef& g, float4 p0, V3 rp, V3 rd, V3& pos, V3& nr
 		if(!rotated) {
 			distance = hit_box(rp, rd, opos, dim, pos, nrm);
 		} else {
-			float4 ri = g.plane(G_ROTINV);
+			v4f ri = g.plane(G_ROTINV);
 			V3 lp = rp - opos;
 			V3 le = lp + rd;
 			lp = rotate(ri, lp);
@@ -274,7 +304,7 @@ PT_DEV float intersect(const GeoRef& g, float4 p0, V3 rp, V3 rd, V3& pos, V3& nr
 			V3 ld = normalise(le - lp);
 			distance = hit_box(lp, ld, v3(0, 0, 0), dim, pos, nrm);
 			if(distance != -1) {
-				float4 r = g.plane(G_ROT);
+				v4f r = g.plane(G_ROT);
 				pos = rotate(r, pos);
 				pos = pos + opos;
 				nrm = rotate(r, nrm);
@@ -364,16 +394,26 @@ PT_DEV bool walk_next(const Grid& g, Walk& w) {
 #define PT_HASH_INIT 1469598103934665603ULL
 PT_DEV uint64_t hash_cell(uint64_t h, int index) { return (h ^ (uint64_t)(uint32_t)(index + 1)) * 1099511628211ULL; }
 
+PT_DEV Surface surface_of(const Scene& sc, int index) {
+	Surface m;
+	m.m0 = sc.mat[(size_t)M_COLOR * sc.n + index];
+	m.m1 = sc.mat[(size_t)M_EMIT * sc.n + index];
+	m.rough = sc.geo[(size_t)G_SCALE * sc.n + index].w;
+	return m;
+}
+
 // castRayAll (code/raycast.cpp:895-926): every entity, bounding-sphere prefilter first.  The
 // traverse-init the reference runs before it (code/raycast.cpp:1101) only matters for `outside`.
-PT_DEV int cast_all(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm) {
+// The loop index is wave-uniform, so the entity records arrive through scalar loads, and the
+// surface of the winning entity is latched on the way instead of being gathered afterwards.
+PT_DEV int cast_all(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface& surf) {
 	V3 entry;
 	if(!grid_entry(sc.grid, rp, rd, entry)) return 0;   // outside: only planes would be tested, and there are none
 	int id = 0;
 	float best = 3.402823466e+38f;
 	for(int i = 0; i < sc.n; i++) {
 		GeoRef g = { sc.geo, sc.n, i };
-		float4 p0 = g.plane(G_POS);
+		v4f p0 = g.plane(G_POS);
 		if(touches_sphere(rp, rd, v3(p0.x, p0.y, p0.z), p0.w)) {
 			V3 p, q;
 			float distance = intersect(g, p0, rp, rd, p, q);
@@ -382,6 +422,7 @@ PT_DEV int cast_all(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm) {
 				id = i + 1;
 				hpos = p;
 				hnrm = q;
+				surf = surface_of(sc, i);
 			}
 		}
 	}
@@ -392,7 +433,7 @@ PT_DEV int cast_all(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm) {
 // stop at the first cell that produced one.  Items are in ascending id, so on equal distance the
 // lowest id wins, as in the reference.
 template <bool HASH>
-PT_DEV int cast_grid(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, uint64_t& hash) {
+PT_DEV int cast_grid(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface& surf, uint64_t& hash) {
 	V3 start;
 	if(!grid_entry(sc.grid, rp, rd, start)) return 0;
 	Walk w;
@@ -406,7 +447,7 @@ PT_DEV int cast_grid(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, uint64_t
 		for(uint32_t k = k0; k < k1; k++) {
 			int oi = (int)sc.cell_items[k];
 			GeoRef g = { sc.geo, sc.n, oi };
-			float4 p0 = g.plane(G_POS);
+			v4f p0 = g.plane(G_POS);
 			V3 p, q;
 			float distance = intersect(g, p0, rp, rd, p, q);
 			if(distance > 0 && distance < best && inside_box(p, w.lo, w.hi)) {
@@ -418,13 +459,14 @@ PT_DEV int cast_grid(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, uint64_t
 		}
 		if(id != 0) break;
 	} while(walk_next(sc.grid, w));
+	if(id != 0) surf = surface_of(sc, id - 1);
 	return id;
 }
 
 template <bool HASH>
-PT_DEV int cast(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, uint64_t& hash) {
-	if(sc.brute) return cast_all(sc, rp, rd, hpos, hnrm);
-	return cast_grid<HASH>(sc, rp, rd, hpos, hnrm, hash);
+PT_DEV int cast(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface& surf, uint64_t& hash) {
+	if(sc.brute) return cast_all(sc, rp, rd, hpos, hnrm, surf);
+	return cast_grid<HASH>(sc, rp, rd, hpos, hnrm, surf, hash);
 }
 
 // ---- optics (code/raycast.cpp:194-242) -----------------------------------------------------------
@@ -456,10 +498,9 @@ PT_DEV float fresnel(V3 incident, V3 normal, float ior) {
 
 // ---- one bounce of shading (code/raycast.cpp:1109-1260) -----------------------------------------
 // Returns true when the path continues.  rp/rd are updated to the next ray.
-PT_DEV bool shade(const Scene& sc, const Frame& fr, int id, V3 hp, V3 hn, int bounce, V3& rp, V3& rd, V3& att, V3& col, Rng& rng) {
+PT_DEV bool shade(const Scene& sc, FrameRef fr, int id, const Surface& surf, V3 hp, V3 hn, int bounce, V3& rp, V3& rd, V3& att, V3& col, Rng& rng) {
 	if(id != 0) {
-		float4 m0 = sc.mat[(size_t)M_COLOR * sc.n + (id - 1)];
-		float4 m1 = sc.mat[(size_t)M_EMIT * sc.n + (id - 1)];
+		v4f m0 = surf.m0, m1 = surf.m1;
 		V3 albedo = v3(m0.x, m0.y, m0.z), emit = v3(m1.x, m1.y, m1.z);
 		float refl = m0.w, ior = m1.w;
 		if(!is_zero(emit)) col = col + att * emit;
@@ -483,7 +524,7 @@ PT_DEV bool shade(const Scene& sc, const Frame& fr, int id, V3 hp, V3 hn, int bo
 			V3 spec = v3(0, 0, 0), diff = v3(0, 0, 0);
 			if(refl != 0.0f) spec = mirror(rd, hn);
 			if(refl != 1.0f) {
-				float4 t = sc.dirs[rng_bounded<20000>(rng)];
+				v4f t = sc.dirs[rng_bounded<20000>(rng)];
 				diff = v3(t.x, t.y, t.z);
 				if(dot(diff, hn) < 0) diff = mirror(diff, hn);
 			}
@@ -492,7 +533,7 @@ PT_DEV bool shade(const Scene& sc, const Frame& fr, int id, V3 hp, V3 hn, int bo
 			rd = in;                                     // not normalised when 0 < refl < 1, as in the reference
 			float cosine = blend(1 - refl, 1, dot(in, hn));
 			att = ((att * albedo) / 3.14159274101257324f) * cosine;
-			float rough = sc.geo[(size_t)G_SCALE * sc.n + (id - 1)].w;
+			float rough = surf.rough;
 			if(rough != 0.0f) {                          // Oren-Nayar (code/raycast.cpp:1199-1221)
 				float r2 = rough * rough;
 				float a = 1 - 0.5f * (r2 / (r2 + 0.33f));
@@ -512,38 +553,41 @@ PT_DEV bool shade(const Scene& sc, const Frame& fr, int id, V3 hp, V3 hn, int bo
 		}
 		return !is_zero(att);
 	} else if(bounce == 0) {
-		col = col + fr.bg;
+		col = col + ld3(fr->bg);
 		return false;
 	} else {
-		float ld = dot(rd, fr.light_dir);
+		float ld = dot(rd, ld3(fr->light_dir));
 		ld = ld < 0 ? 0.0f : ld;
-		col = col + att * (fr.ambient + fr.light * ld);
+		col = col + att * (ld3(fr->ambient) + ld3(fr->light) * ld);
 		return false;
 	}
 }
 
 // ---- camera (code/raycast.cpp:1040-1084) --------------------------------------------------------
-PT_DEV V3 pixel_origin(const Frame& fr, int x, int y) {
-	float px = (float)x / (float)fr.width, py = (float)y / (float)fr.height;
-	return (fr.top_left + fr.right_width * px) + fr.down_height * py;
+PT_DEV V3 pixel_origin(FrameRef fr, int x, int y) {
+	float px = (float)x / (float)fr->width, py = (float)y / (float)fr->height;
+	return (ld3(fr->top_left) + ld3(fr->right_width) * px) + ld3(fr->down_height) * py;
 }
-PT_DEV void camera_ray(const Scene& sc, const Frame& fr, V3 origin, float2 s, int lens_index, V3& rp, V3& rd) {
-	rp = (origin + fr.right_px * s.x) + fr.down_px * s.y;
-	if(fr.aperture == 0.0f) {
-		rd = normalise(rp - fr.cam_pos);
+PT_DEV void camera_ray(const Scene& sc, FrameRef fr, V3 origin, v2f s, int lens_index, V3& rp, V3& rd) {
+	rp = (origin + ld3(fr->right_px) * s.x) + ld3(fr->down_px) * s.y;
+	V3 cam = ld3(fr->cam_pos);
+	float aperture = fr->aperture;
+	if(aperture == 0.0f) {
+		rd = normalise(rp - cam);
 	} else {
 		V3 focal = v3(0, 0, 0);
-		V3 through = rp - fr.cam_pos;
-		V3 plane_pos = fr.cam_pos + fr.cam_dir * fr.focal_distance;
-		float a = dot(fr.back, through);                     // linePlaneIntersection, code/rt_math.cpp:2343-2359
+		V3 back = ld3(fr->back);
+		V3 through = rp - cam;
+		V3 plane_pos = cam + ld3(fr->cam_dir) * fr->focal_distance;
+		float a = dot(back, through);                        // linePlaneIntersection, code/rt_math.cpp:2343-2359
 		if(a != 0) {
-			float distance = dot(fr.back, (plane_pos - rp)) / a;
+			float distance = dot(back, (plane_pos - rp)) / a;
 			if(distance >= 0) focal = rp + through * distance;
 		}
-		float2 lens = sc.disc[lens_index % 20000];
-		float ox = lens.x * fr.aperture;
-		float oy = lens.y * fr.aperture;
-		rp = rp + (fr.right * ox + fr.down * oy);
+		v2f lens = sc.disc[lens_index % 20000];
+		float ox = lens.x * aperture;
+		float oy = lens.y * aperture;
+		rp = rp + (ld3(fr->right) * ox + ld3(fr->down) * oy);
 		rd = normalise(focal - rp);
 	}
 }
@@ -551,15 +595,15 @@ PT_DEV void camera_ray(const Scene& sc, const Frame& fr, V3 origin, float2 s, in
 // Stream ids of the per-sample seed policy: one stream per pixel (lens table start) and one per
 // camera sample; `stride` bounds the samples a tile may hold.
 #define PT_STREAM_STRIDE 4096ULL
-PT_DEV int lens_start(const Frame& fr, int x, int y) {
+PT_DEV int lens_start(FrameRef fr, int x, int y) {
 	Rng r;
-	rng_seed(r, fr.seed, (uint64_t)y * (uint64_t)fr.width + (uint64_t)x);
+	rng_seed(r, fr->seed, (uint64_t)y * (uint64_t)fr->width + (uint64_t)x);
 	return (int)rng_bounded<20000>(r);
 }
-PT_DEV void sample_stream(const Frame& fr, int x, int y, int si, uint64_t pass, Rng& r) {
-	uint64_t wh = (uint64_t)fr.width * (uint64_t)fr.height;
-	uint64_t pix = (uint64_t)y * (uint64_t)fr.width + (uint64_t)x;
-	rng_seed(r, fr.seed + pass, wh + pix * PT_STREAM_STRIDE + (uint64_t)si);
+PT_DEV void sample_stream(FrameRef fr, int x, int y, int si, uint64_t pass, Rng& r) {
+	uint64_t wh = (uint64_t)fr->width * (uint64_t)fr->height;
+	uint64_t pix = (uint64_t)y * (uint64_t)fr->width + (uint64_t)x;
+	rng_seed(r, fr->seed + pass, wh + pix * PT_STREAM_STRIDE + (uint64_t)si);
 }
 
 }  // namespace ptd

@@ -17,6 +17,9 @@ namespace {
 
 constexpr int kBlock = 256;            // 4 wavefronts; waves never synchronise with each other
 constexpr int kGroup = 64;             // pixels per pool refill = one 8x8 image tile
+#ifndef PT_TRACE_WAVES_PER_SIMD
+#define PT_TRACE_WAVES_PER_SIMD 4     // register budget of the trace kernel: 128 VGPRs
+#endif
 
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ int lanes_below(uint64_t mask) {
@@ -26,10 +29,14 @@ __device__ __forceinline__ int lanes_below(uint64_t mask) {
 // Lane states of the trace loop.
 enum { NEED_PIXEL = 0, NEED_PATH = 1, IN_FLIGHT = 2, RETIRED = 3 };
 
-__global__ __launch_bounds__(kBlock) void pt_k_trace(ptl::TraceJob job) {
-	const Scene& sc = job.scene;
-	const Frame& fr = job.frame;
+// BRUTE selects the cast at compile time (castRayAll for scenes under the brute-force threshold,
+// the grid walk otherwise) so that the small-scene kernel does not carry the DDA's registers.
+template <bool BRUTE>
+__global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(ptl::TraceJob job) {
+	const Scene sc = scene_view(job.scene);
+	const FrameRef fr = (FrameRef)job.frame;
 	const int lane = lane_id();
+	const int width = fr->width, height = fr->height, tile_w = fr->tile_w, max_bounces = fr->max_bounces;
 
 	// wave-uniform tile pool
 	int pool_next = 0, pool_end = 0;
@@ -72,9 +79,9 @@ __global__ __launch_bounds__(kBlock) void pt_k_trace(ptl::TraceJob job) {
 				int tile = local_tile * job.part_count + job.part_index;
 				px = (tile % job.tiles_x) * 8 + (j & 7);
 				py = (tile / job.tiles_x) * 8 + (j >> 3);
-				if(px < fr.width && py < fr.height) {
-					out_index = job.compact ? (size_t)slot : (size_t)py * (size_t)fr.width + (size_t)px;
-					int t = (py % fr.tile_w) * fr.tile_w + (px % fr.tile_w);
+				if(px < width && py < height) {
+					out_index = job.compact ? (size_t)slot : (size_t)py * (size_t)width + (size_t)px;
+					int t = (py % tile_w) * tile_w + (px % tile_w);
 					sample_base = sc.offsets[t];
 					n_samples = sc.offsets[t + 1] - sample_base;
 					if(n_samples == 0) {
@@ -84,7 +91,7 @@ __global__ __launch_bounds__(kBlock) void pt_k_trace(ptl::TraceJob job) {
 					} else {
 						if(job.frame_index < 0) { si = 0; si_end = n_samples; pass = 0; }
 						else { si = job.frame_index % n_samples; si_end = si + 1; pass = (uint64_t)(job.frame_index / n_samples); }
-						lens = fr.aperture != 0.0f ? lens_start(fr, px, py) : 0;
+						lens = fr->aperture != 0.0f ? lens_start(fr, px, py) : 0;
 						origin = pixel_origin(fr, px, py);
 						sum = v3(0, 0, 0);
 						state = NEED_PATH;
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void pt_k_trace(ptl::TraceJob job) {
 
 		// ---- stage 1: generate the camera ray of the next sample (code/raycast.cpp:1059-1090) ---
 		if(state == NEED_PATH) {
-			float2 s = sc.samples[sample_base + si];
+			v2f s = sc.samples[sample_base + si];
 			camera_ray(sc, fr, origin, s, lens + si, rp, rd);
 			sample_stream(fr, px, py, si, pass, rng);
 			att = v3(1, 1, 1);
@@ -113,12 +120,14 @@ __global__ __launch_bounds__(kBlock) void pt_k_trace(ptl::TraceJob job) {
 		// ---- stage 2+3: extend one ray and shade the hit (code/raycast.cpp:1092-1261) ---------
 		if(state == IN_FLIGHT) {
 			V3 hp = v3(0, 0, 0), hn = v3(0, 0, 0);
+			Surface surf;
+			surf.m0 = (v4f)(0.0f); surf.m1 = (v4f){ 0.0f, 0.0f, 0.0f, 1.0f }; surf.rough = 0;
 			uint64_t unused = 0;
-			int id = cast<false>(sc, rp, rd, hp, hn, unused);
+			int id = BRUTE ? cast_all(sc, rp, rd, hp, hn, surf) : cast_grid<false>(sc, rp, rd, hp, hn, surf, unused);
 			casts++;
-			bool alive = shade(sc, fr, id, hp, hn, bounce, rp, rd, att, col, rng);
+			bool alive = shade(sc, fr, id, surf, hp, hn, bounce, rp, rd, att, col, rng);
 			bounce++;
-			if(!alive || bounce >= fr.max_bounces) {
+			if(!alive || bounce >= max_bounces) {
 				sum = sum + clamp_hi(col, 1.0f);            // per-sample clamp before averaging (code/raycast.cpp:1263)
 				si++;
 				state = NEED_PATH;
@@ -151,21 +160,24 @@ __global__ __launch_bounds__(kBlock) void pt_k_trace(ptl::TraceJob job) {
 
 // Debug pass: entity hit by, and grid cells visited by, the primary ray of camera sample 0 of
 // every pixel.  Same device functions as the trace kernel.
-__global__ __launch_bounds__(kBlock) void pt_k_primary(Scene sc, Frame fr, int32_t* hit_id, uint64_t* cell_hash) {
+__global__ __launch_bounds__(kBlock) void pt_k_primary(ptl::SceneDev scene, const ptl::FrameDev* frame, int32_t* hit_id, uint64_t* cell_hash) {
+	const Scene sc = scene_view(scene);
+	const FrameRef fr = (FrameRef)frame;
 	int i = blockIdx.x * kBlock + threadIdx.x;
-	if(i >= fr.width * fr.height) return;
-	int x = i % fr.width, y = i / fr.width;
-	int t = (y % fr.tile_w) * fr.tile_w + (x % fr.tile_w);
+	if(i >= fr->width * fr->height) return;
+	int x = i % fr->width, y = i / fr->width;
+	int t = (y % fr->tile_w) * fr->tile_w + (x % fr->tile_w);
 	int base = sc.offsets[t];
 	int count = sc.offsets[t + 1] - base;
 	int id = -1;
 	uint64_t h = 0;
 	if(count > 0) {
 		V3 rp, rd, hp, hn;
-		int lens = fr.aperture != 0.0f ? lens_start(fr, x, y) : 0;
+		int lens = fr->aperture != 0.0f ? lens_start(fr, x, y) : 0;
 		camera_ray(sc, fr, pixel_origin(fr, x, y), sc.samples[base], lens, rp, rd);
 		h = PT_HASH_INIT;
-		id = cast<true>(sc, rp, rd, hp, hn, h);
+		Surface surf;
+		id = cast<true>(sc, rp, rd, hp, hn, surf, h);
 		if(sc.brute) h = 0;
 	}
 	if(hit_id) hit_id[i] = id;
@@ -173,15 +185,17 @@ __global__ __launch_bounds__(kBlock) void pt_k_primary(Scene sc, Frame fr, int32
 }
 
 // One-ray queries (picking, focal-distance probe) and the intersection-level parity tests.
-__global__ __launch_bounds__(kBlock) void pt_k_cast(Scene sc, const float* origins, const float* dirs, int n,
+__global__ __launch_bounds__(kBlock) void pt_k_cast(ptl::SceneDev scene, const float* origins, const float* dirs, int n,
                                                     int32_t* hit_id, float* hit_pos, float* hit_nrm) {
+	const Scene sc = scene_view(scene);
 	int i = blockIdx.x * kBlock + threadIdx.x;
 	if(i >= n) return;
 	V3 rp = v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
 	V3 rd = v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
 	V3 hp = v3(0, 0, 0), hn = v3(0, 0, 0);
 	uint64_t unused = 0;
-	int id = cast<false>(sc, rp, rd, hp, hn, unused);
+	Surface surf;
+	int id = cast<false>(sc, rp, rd, hp, hn, surf, unused);
 	if(id == 0) { hp = v3(0, 0, 0); hn = v3(0, 0, 0); }
 	hit_id[i] = id;
 	if(hit_pos) { hit_pos[3 * i] = hp.x; hit_pos[3 * i + 1] = hp.y; hit_pos[3 * i + 2] = hp.z; }
@@ -218,8 +232,9 @@ namespace ptl {
 const char* trace_kernel_name() { return "pt_k_trace"; }
 
 hipError_t launch_trace(const TraceJob& job, hipStream_t stream, int* grid_blocks_out) {
-	static int blocks_per_cu = 0, cus = 0;
-	if(blocks_per_cu == 0) {
+	static int blocks_per_cu[2] = { 0, 0 }, cus = 0;
+	const int which = job.scene.brute ? 1 : 0;
+	if(blocks_per_cu[which] == 0) {
 		int dev = 0;
 		hipError_t e = hipGetDevice(&dev);
 		if(e != hipSuccess) return e;
@@ -228,25 +243,26 @@ hipError_t launch_trace(const TraceJob& job, hipStream_t stream, int* grid_block
 		if(e != hipSuccess) return e;
 		cus = prop.multiProcessorCount;
 		int b = 0;
-		e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, pt_k_trace, kBlock, 0);
+		e = which ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, pt_k_trace<true>, kBlock, 0)
+		          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, pt_k_trace<false>, kBlock, 0);
 		if(e != hipSuccess) return e;
-		blocks_per_cu = b > 0 ? b : 1;
+		blocks_per_cu[which] = b > 0 ? b : 1;
 	}
 	hipError_t e = hipMemsetAsync(job.group_counter, 0, sizeof(uint32_t), stream);
 	if(e != hipSuccess) return e;
 	// persistent launch: every resident wave pulls 64-pixel tiles until the partition is drained
-	long waves_needed = job.n_groups;
-	long blocks = (waves_needed + 3) / 4;
-	long resident = (long)cus * blocks_per_cu;
+	long blocks = ((long)job.n_groups + 3) / 4;
+	long resident = (long)cus * blocks_per_cu[which];
 	if(blocks > resident) blocks = resident;
 	if(blocks < 1) blocks = 1;
 	if(grid_blocks_out) *grid_blocks_out = (int)blocks;
-	hipLaunchKernelGGL(pt_k_trace, dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
+	if(which) hipLaunchKernelGGL(pt_k_trace<true>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
+	else hipLaunchKernelGGL(pt_k_trace<false>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
 	return hipGetLastError();
 }
 
-hipError_t launch_primary_aov(const SceneDev& sc, const FrameDev& fr, int32_t* hit_id, uint64_t* cell_hash, hipStream_t stream) {
-	int n = fr.width * fr.height;
+hipError_t launch_primary_aov(const SceneDev& sc, const FrameDev* fr, int width, int height, int32_t* hit_id, uint64_t* cell_hash, hipStream_t stream) {
+	int n = width * height;
 	hipLaunchKernelGGL(pt_k_primary, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, sc, fr, hit_id, cell_hash);
 	return hipGetLastError();
 }

@@ -38,7 +38,7 @@ struct FrameDev {
 // tiles t with t % part_count == part_index.
 struct TraceJob {
 	SceneDev scene;
-	FrameDev frame;
+	const FrameDev* frame;      // device copy of the per-frame constants
 	float* fb;                  // row-major image, or tile-major [local tile][64][3] when compact
 	float* accum;               // progressive accumulation buffer (same layout as fb), may be null
 	uint32_t* group_counter;    // device word, zeroed by the launcher
@@ -52,7 +52,7 @@ struct TraceJob {
 };
 
 hipError_t launch_trace(const TraceJob& job, hipStream_t stream, int* grid_blocks_out);
-hipError_t launch_primary_aov(const SceneDev& sc, const FrameDev& fr, int32_t* hit_id, uint64_t* cell_hash, hipStream_t stream);
+hipError_t launch_primary_aov(const SceneDev& sc, const FrameDev* fr, int width, int height, int32_t* hit_id, uint64_t* cell_hash, hipStream_t stream);
 hipError_t launch_cast(const SceneDev& sc, const float* origins, const float* dirs, int n, int32_t* hit_id,
                        float* hit_pos, float* hit_nrm, hipStream_t stream);
 hipError_t launch_srgb8(const float* rgb, size_t n, uint8_t* out, hipStream_t stream);

@@ -1,0 +1,17 @@
+#!/bin/bash
+# builds pathtracer_amd/variant_<name>.so with extra compiler flags (A/B timing of kernel variants)
+# usage: profiles/build_variant.sh <name> [extra hipcc flags...]
+name=$1; shift
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt "$@" \
+	-Iinclude -Ipathtracer_amd/csrc pathtracer_amd/csrc/pt_api.cpp pathtracer_amd/csrc/pt_host.cpp pathtracer_amd/csrc/pt_kernels.hip \
+	-o pathtracer_amd/variant_$name.so -Rpass-analysis=kernel-resource-usage > /tmp/variant_$name.log 2>&1
+rc=$?
+grep -E "error" /tmp/variant_$name.log | head -5
+python3 - "$name" <<'PY'
+import re, sys
+log = open(f"/tmp/variant_{sys.argv[1]}.log").read()
+for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+).*?SGPRs Spill: (\d+).*?VGPRs Spill: (\d+)", log, re.S):
+    if "trace" in m.group(1):
+        print(f"  {sys.argv[1]:12s} {m.group(1)[-28:]:28s} vgpr {m.group(2)} scratch {m.group(3)} occ {m.group(4)} sgpr-spill {m.group(5)} vgpr-spill {m.group(6)}")
+PY
+exit $rc
