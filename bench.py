@@ -30,6 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from pathtracer_amd import api, scenes  # noqa: E402
+from pathtracer_amd import dist as ptdist  # noqa: E402
 
 # fp32 operations per event, from the reference source (one add, mul, divide, sqrt or compare each).
 FLOP_WEIGHTS = {
@@ -146,9 +147,8 @@ def main():
     stream = torch.cuda.current_stream()
     if world_size > 1:
         # tile-major partition buffers; rank 0 gathers them and assembles the image
-        floats_max = torch.tensor([part_floats], device="cuda")
-        dist.all_reduce(floats_max, op=dist.ReduceOp.MAX)
-        stride = int(floats_max.item())
+        stride = ptdist.partition_stride(st.width, st.height, world_size)
+        assert part_floats <= stride
         mine = torch.zeros(stride, dtype=torch.float32, device="cuda")
         gathered = torch.empty(world_size * stride, dtype=torch.float32, device="cuda") if rank == 0 else None
         image = torch.empty(st.height * st.width * 3, dtype=torch.float32, device="cuda") if rank == 0 else None
@@ -160,11 +160,9 @@ def main():
             r.trace(d_rgb=image.data_ptr(), stream=stream.cuda_stream, sync=False)
         else:
             r.trace(d_rgb=mine.data_ptr(), stream=stream.cuda_stream, sync=False)
+            ptdist.gather_parts(mine, gathered, stride, rank, world_size)
             if rank == 0:
-                dist.gather(mine, [gathered[i * stride:(i + 1) * stride] for i in range(world_size)], dst=0)
                 r.assemble(gathered.data_ptr(), stride, world_size, st.width, st.height, image.data_ptr(), stream.cuda_stream)
-            else:
-                dist.gather(mine, None, dst=0)
 
     for _ in range(args.warmup):
         step()

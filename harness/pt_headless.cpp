@@ -1,0 +1,161 @@
+// Headless Linux harness for the render core: plays the part of the reference's frame function
+// (code/app.cpp:1127-1461) without a window.  It starts a render, polls progress once per "frame",
+// optionally aborts, waits, and writes the image - all through the C ABI of include/pt_api.h, the
+// same calls the OpenGL editor would make in place of its start / poll / abort blocks.
+//
+//   pt_headless [--scene default|FILE.scene] [--size WxH] [--spp N] [--bounces N] [--grid-hint N]
+//               [--seed N] [--gpus 0,1,...] [--out IMAGE.ppm] [--pfm IMAGE.pfm] [--poll-ms N]
+//               [--abort-after SECONDS] [--quiet]
+//
+// With several GPUs every device gets its own context and a round-robin share of the image's 8x8
+// tiles; all contexts fill the one caller-owned image.  Prints one JSON line with the metrics the
+// reference shows in its stats panel (code/app.cpp:2879-2896): pixels, samples, time, plus Mpaths/s.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "pt_api.h"
+
+static void usage() {
+	fprintf(stderr, "usage: pt_headless [--scene default|FILE.scene] [--size WxH] [--spp N] [--bounces N] [--grid-hint N]\n"
+	                "                   [--seed N] [--gpus 0,1,...] [--out IMAGE.ppm] [--pfm IMAGE.pfm] [--poll-ms N]\n"
+	                "                   [--abort-after SECONDS] [--quiet]\n");
+}
+
+// Screenshot encoding of the reference (code/app.cpp:1541-1547, code/rt_math.cpp:3634-3640).
+static unsigned char encode_srgb8(float v) {
+	if(v < 0.0031308f) v *= 12.92f;
+	else v = 1.055f * powf(v, 1.0f / 2.4f) - 0.055f;
+	return (unsigned char)(char)(int)roundf(v * 255);
+}
+
+int main(int argc, char** argv) {
+	std::string scene = "default", out_ppm, out_pfm;
+	std::vector<int> gpus = { 0 };
+	pt_settings st;
+	pt_default_settings(&st);
+	int poll_ms = 16;
+	double abort_after = -1;
+	bool quiet = false;
+	for(int i = 1; i < argc; i++) {
+		std::string a = argv[i];
+		auto next = [&]() -> const char* { if(i + 1 >= argc) { usage(); exit(2); } return argv[++i]; };
+		if(a == "--scene") scene = next();
+		else if(a == "--size") { if(sscanf(next(), "%dx%d", &st.width, &st.height) != 2) { usage(); return 2; } }
+		else if(a == "--spp") st.spp_wanted = atoi(next());
+		else if(a == "--bounces") st.max_bounces = atoi(next());
+		else if(a == "--grid-hint") st.grid_hint = atoi(next());
+		else if(a == "--seed") st.seed = strtoull(next(), 0, 10);
+		else if(a == "--out") out_ppm = next();
+		else if(a == "--pfm") out_pfm = next();
+		else if(a == "--poll-ms") poll_ms = atoi(next());
+		else if(a == "--abort-after") abort_after = atof(next());
+		else if(a == "--quiet") quiet = true;
+		else if(a == "--gpus") {
+			gpus.clear();
+			std::string l = next();
+			for(size_t p = 0; p < l.size();) { size_t q = l.find(',', p); if(q == std::string::npos) q = l.size(); gpus.push_back(atoi(l.substr(p, q - p).c_str())); p = q + 1; }
+		}
+		else { usage(); return 2; }
+	}
+
+	pt_world world;
+	std::vector<pt_object> objects;
+	if(scene == "default") {
+		objects.resize(2);
+		int n = 0;
+		if(pt_default_scene(&world, objects.data(), 2, &n) != PT_OK) { fprintf(stderr, "pt_default_scene failed\n"); return 1; }
+	} else {
+		int n = 0;
+		if(pt_scene_load(scene.c_str(), &world, nullptr, 0, &n) != PT_OK) { fprintf(stderr, "cannot read scene file %s\n", scene.c_str()); return 1; }
+		objects.resize((size_t)(n > 0 ? n : 1));
+		if(pt_scene_load(scene.c_str(), &world, objects.data(), n, &n) != PT_OK) { fprintf(stderr, "cannot read scene file %s\n", scene.c_str()); return 1; }
+		objects.resize((size_t)n);
+	}
+
+	const int parts = (int)gpus.size();
+	std::vector<pt_ctx*> ctx((size_t)parts, nullptr);
+	for(int p = 0; p < parts; p++) {
+		ctx[(size_t)p] = pt_create(gpus[(size_t)p]);
+		if(!ctx[(size_t)p]) { fprintf(stderr, "pt_create(%d): %s\n", gpus[(size_t)p], pt_last_error(nullptr)); return 1; }
+	}
+	std::vector<float> image((size_t)st.width * st.height * 3, 0.0f);
+
+	auto t0 = std::chrono::steady_clock::now();
+	for(int p = 0; p < parts; p++) {
+		pt_settings s = st;
+		s.part_index = p;
+		s.part_count = parts;
+		int rc = pt_render_start(ctx[(size_t)p], &world, objects.data(), (int)objects.size(), &s, image.data());
+		if(rc != PT_OK) { fprintf(stderr, "pt_render_start: %s\n", pt_last_error(ctx[(size_t)p])); return 1; }
+	}
+	// the application's frame loop: poll once per frame, abort on request
+	bool aborted = false;
+	for(;;) {
+		bool all_done = true;
+		float fraction = 0;
+		for(int p = 0; p < parts; p++) {
+			pt_progress info;
+			int rc = pt_render_progress(ctx[(size_t)p], &info);
+			if(rc != PT_OK) { fprintf(stderr, "render failed: %s\n", pt_last_error(ctx[(size_t)p])); return 1; }
+			all_done = all_done && info.done;
+			fraction += info.fraction / parts;
+		}
+		double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		if(!quiet) fprintf(stderr, "\r%5.1f %%  %.3f s", fraction * 100, elapsed);
+		if(all_done) break;
+		if(abort_after >= 0 && !aborted && elapsed >= abort_after) {
+			for(int p = 0; p < parts; p++) pt_render_abort(ctx[(size_t)p]);
+			aborted = true;
+		}
+		std::this_thread::sleep_for(std::chrono::milliseconds(poll_ms));
+	}
+	if(!quiet) fprintf(stderr, "\n");
+	unsigned long long paths = 0, rays = 0, pixels = 0;
+	double seconds = 0, kernel_ms = 0;
+	int was_aborted = 0;
+	for(int p = 0; p < parts; p++) {
+		int rc = pt_render_wait(ctx[(size_t)p]);
+		if(rc != PT_OK) { fprintf(stderr, "render failed: %s\n", pt_last_error(ctx[(size_t)p])); return 1; }
+		pt_progress info;
+		pt_render_progress(ctx[(size_t)p], &info);
+		pt_stats stats;
+		pt_get_stats(ctx[(size_t)p], &stats);
+		paths += stats.paths; rays += stats.rays; pixels += stats.pixels;
+		seconds = info.seconds > seconds ? info.seconds : seconds;
+		kernel_ms = stats.trace_ms > kernel_ms ? stats.trace_ms : kernel_ms;
+		was_aborted |= info.aborted;
+	}
+
+	if(!out_ppm.empty()) {
+		FILE* f = fopen(out_ppm.c_str(), "wb");
+		if(!f) { fprintf(stderr, "cannot write %s\n", out_ppm.c_str()); return 1; }
+		fprintf(f, "P6\n%d %d\n255\n", st.width, st.height);
+		std::vector<unsigned char> bytes(image.size());
+		if(parts == 1 && !was_aborted) {
+			if(pt_present_srgb8(ctx[0], bytes.data()) != PT_OK) { fprintf(stderr, "pt_present_srgb8: %s\n", pt_last_error(ctx[0])); return 1; }
+		} else {
+			for(size_t i = 0; i < image.size(); i++) bytes[i] = encode_srgb8(image[i]);
+		}
+		fwrite(bytes.data(), 1, bytes.size(), f);
+		fclose(f);
+	}
+	if(!out_pfm.empty()) {
+		FILE* f = fopen(out_pfm.c_str(), "wb");
+		if(!f) { fprintf(stderr, "cannot write %s\n", out_pfm.c_str()); return 1; }
+		fprintf(f, "PF\n%d %d\n-1.0\n", st.width, st.height);
+		for(int y = st.height - 1; y >= 0; y--) fwrite(image.data() + (size_t)y * st.width * 3, sizeof(float), (size_t)st.width * 3, f);
+		fclose(f);
+	}
+	printf("{\"scene\": \"%s\", \"width\": %d, \"height\": %d, \"spp_wanted\": %d, \"max_bounces\": %d, \"objects\": %d, \"gpus\": %d, "
+	       "\"pixels\": %llu, \"paths\": %llu, \"rays\": %llu, \"seconds\": %.6f, \"kernel_ms\": %.3f, \"mpaths_per_s\": %.1f, \"aborted\": %d}\n",
+	       scene.c_str(), st.width, st.height, st.spp_wanted, st.max_bounces, (int)objects.size(), parts, pixels, paths, rays, seconds,
+	       kernel_ms, seconds > 0 ? paths / seconds / 1e6 : 0.0, was_aborted);
+	for(int p = 0; p < parts; p++) pt_destroy(ctx[(size_t)p]);
+	return 0;
+}

@@ -201,8 +201,17 @@ int pt_present_srgb8(pt_ctx* ctx, uint8_t* rgb8);
  * d_parts: part_count buffers, stride_floats apart; all pointers are device pointers.
  */
 int pt_partition_floats(const pt_ctx* ctx, size_t* floats);
+/* Number of 8x8 tiles partition `part_index` of `part_count` owns in a width x height image
+ * (its buffer holds that many times 192 floats); negative on bad arguments. Pure arithmetic. */
+int pt_partition_tiles(int width, int height, int part_index, int part_count);
 int pt_assemble(pt_ctx* ctx, const float* d_parts, size_t stride_floats, int part_count, int width,
                 int height, float* d_rgb, void* hip_stream);
+
+/* Scene files in the reference's own format (saveScene / loadScene, code/raycast.cpp:1578-1604):
+ * a 224-byte World image followed by 172-byte Object images.  pt_scene_load with objects == NULL
+ * only reports the object count. */
+int pt_scene_load(const char* path, pt_world* world, pt_object* objects, int capacity, int* count);
+int pt_scene_save(const char* path, const pt_world* world, const pt_object* objects, int count);
 
 /* ---- host stages, exported so they can be checked without a GPU -------------------------- */
 

@@ -67,6 +67,8 @@ def load_ref():
     _sig(lib, "ref_primary_hits", None, IP)
     _sig(lib, "ref_srgb8", None, C.c_int, FP, U8P)
     _sig(lib, "ref_sizeof", C.c_int, C.c_int)
+    _sig(lib, "ref_save_scene", None, C.c_char_p)
+    _sig(lib, "ref_load_scene", C.c_int, C.c_char_p, C.POINTER(pt_world), C.POINTER(pt_object), C.c_int)
     return lib
 
 

@@ -46,6 +46,7 @@ sed -e '1276s/vec3i(10,10,10)/vec3i(ref_grid_hint,ref_grid_hint,ref_grid_hint)/'
     -e '1331s/settings->gridBuffer;/settings->gridBuffer + settings->gridBufferCount;/' "$C/app.cpp" \
 	| sed -n '1161,1357p' > "$TMP/app_setup_fixed.inc"
 sed -n '1359,1419p'  "$C/app.cpp"     > "$TMP/app_jobs.inc"
+sed -n '1578,1604p'  "$C/raycast.cpp" > "$TMP/rc_scenefile.inc"
 sed -n '351,353p;3634,3640p' "$C/rt_math.cpp" > /dev/null   # (present in math_patched.inc; listed for the reader)
 
 g++ -std=gnu++14 -O2 -fpermissive -w -ffp-contract=off -fPIC -shared \

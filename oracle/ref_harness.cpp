@@ -40,6 +40,8 @@ static inline uint64_t ref_rdtsc_hook() { return g_ref_job_seed; }
 #include "rc_core.inc"
 #include "rc_defobj.inc"
 #include "rc_precalc.inc"
+struct EntityUI;                 /* loadScene takes one and never touches it */
+#include "rc_scenefile.inc"
 
 struct RefAppData {
 	RaytraceSettings settings;
@@ -421,6 +423,32 @@ void ref_primary_hits(int32_t* ids) {
 /* Screenshot encoding of one value (code/app.cpp:1541-1547, code/rt_math.cpp:3634-3640). */
 void ref_srgb8(int n, const float* lin, uint8_t* out) {
 	for(int i = 0; i < n; i++) out[i] = (uint8_t)(char)colorFloatToInt(floatToSrgb(lin[i]));
+}
+
+/* saveScene / loadScene (code/raycast.cpp:1578-1604) on the loaded scene. */
+void ref_save_scene(const char* path) { saveScene(&ad->world, (char*)path); }
+int ref_load_scene(const char* path, pt_world* w, pt_object* objs, int cap) {
+	loadScene(&ad->world, (char*)path, 0);
+	World* world = &ad->world;
+	memset(w, 0, sizeof *w);
+	put3(w->camera.pos, world->camera.pos); put3(w->camera.rot, world->camera.rot);
+	w->camera.fov = world->camera.fov; w->camera.plane_width = world->camera.dim.w;
+	put3(w->background_color, world->backgroundColor); put3(w->ambient_color, world->ambientLightColor);
+	put3(w->light_color, world->globalLightColor);
+	w->light_rot[0] = world->globalLightRot.x; w->light_rot[1] = world->globalLightRot.y;
+	w->focal_distance = world->focalPointDistance; w->aperture = world->apertureSize;
+	for(int i = 0; i < world->objects.count && i < cap; i++) {
+		Object* o = world->objects.data + i;
+		memset(objs + i, 0, sizeof(pt_object));
+		put3(objs[i].pos, o->pos); put3(objs[i].dim, o->dim); put3(objs[i].color, o->color);
+		objs[i].rot[0] = o->rot.w; objs[i].rot[1] = o->rot.x; objs[i].rot[2] = o->rot.y; objs[i].rot[3] = o->rot.z;
+		objs[i].type = o->geometry.type;
+		put3(objs[i].emit_color, o->material.emitColor);
+		objs[i].reflection_mod = o->material.reflectionMod;
+		objs[i].refractive_index = o->material.refractiveIndex;
+		objs[i].roughness = o->material.roughness;
+	}
+	return world->objects.count;
 }
 
 int ref_sizeof(int which) {

@@ -169,6 +169,9 @@ def load_core():
                                  C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32), C.c_int,
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.pt_sync.argtypes = [C.c_void_p]
+    lib.pt_partition_tiles.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.pt_scene_load.argtypes = [C.c_char_p, C.POINTER(pt_world), C.POINTER(pt_object), C.c_int, C.POINTER(C.c_int)]
+    lib.pt_scene_save.argtypes = [C.c_char_p, C.POINTER(pt_world), C.POINTER(pt_object), C.c_int]
     lib.pt_partition_floats.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
     lib.pt_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     return lib
@@ -286,3 +289,23 @@ class Renderer:
         out = np.zeros((s.height, s.width, 3), np.uint8)
         self._check(self.lib.pt_present_srgb8(self.ctx, u8ptr(out)), "pt_present_srgb8")
         return out
+
+
+def save_scene(path, world, objs):
+    """Writes a scene file in the reference application's format."""
+    rc = load_core().pt_scene_save(path.encode(), C.byref(world), object_array(objs), len(objs))
+    if rc != 0:
+        raise PtError(f"pt_scene_save({path}) failed ({rc})")
+
+
+def load_scene(path):
+    lib = load_core()
+    world, n = pt_world(), C.c_int(0)
+    rc = lib.pt_scene_load(path.encode(), C.byref(world), None, 0, C.byref(n))
+    if rc != 0:
+        raise PtError(f"pt_scene_load({path}) failed ({rc})")
+    arr = (pt_object * max(1, n.value))()
+    rc = lib.pt_scene_load(path.encode(), C.byref(world), arr, n.value, C.byref(n))
+    if rc != 0:
+        raise PtError(f"pt_scene_load({path}) failed ({rc})")
+    return world, [arr[i] for i in range(n.value)]

@@ -191,7 +191,7 @@ int prepare(pt_ctx* c) {
 	// image tiling and this context's partition
 	const int tiles_x = (s.width + 7) / 8, tiles_y = (s.height + 7) / 8;
 	const int tiles = tiles_x * tiles_y;
-	c->local_tiles = (tiles - s.part_index + s.part_count - 1) / s.part_count;
+	c->local_tiles = pt_partition_tiles(s.width, s.height, s.part_index, s.part_count);
 	const bool compact = s.part_count > 1;
 	c->fb_floats = compact ? (size_t)c->local_tiles * 64 * 3 : (size_t)s.width * s.height * 3;
 	PT_HIP(c, c->fb.reserve(c->fb_floats * 4));
@@ -619,6 +619,12 @@ int pt_assemble(pt_ctx* c, const float* d_parts, size_t stride_floats, int part_
 	hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
 	PT_HIP(c, ptl::launch_assemble(d_parts, stride_floats, part_count, width, height, d_rgb, s));
 	return PT_OK;
+}
+
+int pt_partition_tiles(int width, int height, int part_index, int part_count) {
+	if(width < 1 || height < 1 || part_count < 1 || part_index < 0 || part_index >= part_count) return PT_ERR_ARG;
+	int tiles = ((width + 7) / 8) * ((height + 7) / 8);
+	return (tiles - part_index + part_count - 1) / part_count;
 }
 
 int pt_partition_floats(const pt_ctx* c, size_t* floats) {

@@ -157,6 +157,13 @@ def main():
     s8 = np.zeros(v.size, np.uint8)
     ref.ref_srgb8(v.size, P(v), s8.ctypes.data_as(U8P))
     out["srgb_in"], out["srgb_out"] = v, s8
+    # a scene file written by the reference's own saveScene (code/raycast.cpp:1578-1588)
+    world, objs = scenes.mixed_scene(seed=21, n=11)
+    st = default_settings(64, 36, 4, 2)
+    ref.ref_pcg_seed(0, 1)
+    ref.ref_scene_setup(C.byref(world), object_array(objs), len(objs), C.byref(st), 1)
+    ref.ref_save_scene(os.path.join(ROOT, "tests", "golden", "mixed12.scene").encode())
+
     path = os.path.join(ROOT, "tests", "golden", "ref_vectors.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

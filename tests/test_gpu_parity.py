@@ -201,6 +201,62 @@ def test_partition_invariance(gpu):
         assert (bits(img) == bits(whole)).all(), parts
 
 
+def test_assemble_on_device(gpu):
+    """The multi-GPU data flow on one GPU: every partition traced into a caller-owned device buffer
+    (as bench.py does with torch tensors), buffers side by side as after the gather, pt_assemble."""
+    import torch
+    from pathtracer_amd import dist as ptdist
+    world, objs = scenes.mixed_scene(seed=7, n=40)
+    w, h = 200, 117
+    whole = gpu.render(world, objs, settings_for("mixed40", w, h, 16, 8))
+    for parts in (2, 4, 8):
+        stride = ptdist.partition_stride(w, h, parts)
+        gathered = torch.full((parts * stride,), -1.0, dtype=torch.float32, device="cuda")
+        image = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
+        stream = torch.cuda.current_stream()
+        for p in range(parts):
+            gpu.prepare(world, objs, settings_for("mixed40", w, h, 16, 8, part_index=p, part_count=parts))
+            assert gpu.partition_floats() <= stride
+            gpu.trace(d_rgb=gathered[p * stride:].data_ptr(), stream=stream.cuda_stream, sync=False)
+            ptdist.gather_parts(gathered[p * stride:(p + 1) * stride], gathered[p * stride:], stride, 0, 1)
+        gpu.assemble(gathered.data_ptr(), stride, parts, w, h, image.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize()
+        gpu.sync()
+        got = image.cpu().numpy().reshape(h, w, 3)
+        assert (bits(got) == bits(whole)).all(), parts
+
+
+def test_headless_harness(gpu, tmp_path):
+    """The C++ harness drives start / progress / wait through the C ABI and writes the image."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "harness", "pt_headless")
+    if not os.path.exists(exe):
+        pytest.fail("harness/pt_headless is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    world, objs = scenes.mixed_scene(seed=7, n=40)
+    scene_file = str(tmp_path / "mixed.scene")
+    api.save_scene(scene_file, world, objs)
+    pfm, ppm = str(tmp_path / "o.pfm"), str(tmp_path / "o.ppm")
+    r = subprocess.run([exe, "--scene", scene_file, "--size", "160x90", "--spp", "16", "--bounces", "8", "--seed", "4242",
+                        "--pfm", pfm, "--out", ppm, "--quiet"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    st = settings_for("mixed40", 160, 90, 16, 8)
+    want = gpu.render(world, objs, st)
+    assert info["paths"] == gpu.stats().paths and info["aborted"] == 0 and info["objects"] == len(objs)
+    raw = open(pfm, "rb").read()
+    got = np.frombuffer(raw[-160 * 90 * 12:], np.float32).reshape(90, 160, 3)[::-1]
+    assert (bits(got) == bits(want)).all()
+    body = open(ppm, "rb").read()
+    assert body.startswith(b"P6") and len(body) >= 160 * 90 * 3
+    # abort path: a long render stopped from the frame loop still ends cleanly
+    r = subprocess.run([exe, "--scene", scene_file, "--size", "1920x1080", "--spp", "256", "--bounces", "32", "--abort-after", "0.02",
+                        "--poll-ms", "2", "--quiet"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "aborted" in r.stdout
+
+
 def test_determinism_and_range_at_full_size(gpu):
     """BASELINE size (1080p, 64 spp, depth 8): two runs are bitwise equal, the image is finite and in
     [0,1], primary ids equal the oracle's, sky rows are exactly the background colour."""
