@@ -71,6 +71,15 @@ def workload(name):
     if name == "dense100k-4k-256spp-d8":
         world, objs = scenes.dense_scene(n=100000, seed=4)
         return world, objs, dict(width=3840, height=2160, spp=256, bounces=8, seed=12345, grid_hint=64)
+    if name == "glass-1080p-16spp-d32":
+        world, objs = scenes.glass_scene(seed=3, per_type=16)
+        return world, objs, dict(width=1920, height=1080, spp=16, bounces=32, seed=12345)
+    if name == "dense100k-1080p-16spp-d8":
+        world, objs = scenes.dense_scene(n=100000, seed=4)
+        return world, objs, dict(width=1920, height=1080, spp=16, bounces=8, seed=12345, grid_hint=64)
+    if name == "dense10k-1080p-16spp-d8":
+        world, objs = scenes.dense_scene(n=10000, seed=4, half_extent=90.0, height=45.0)
+        return world, objs, dict(width=1920, height=1080, spp=16, bounces=8, seed=12345, grid_hint=32)
     raise SystemExit(f"unknown workload {name}")
 
 

@@ -33,7 +33,7 @@ typedef const PT_CONST ptl::FrameDev* FrameRef;
 struct Scene {
 	cf4 geo, mat, dirs;
 	cf2 disc, samples;
-	cu32 cell_start, cell_items;
+	cu32 cell_start, cell_items, obj_range;
 	ci32 offsets;
 	int n, brute;
 	Grid grid;
@@ -42,7 +42,7 @@ __device__ __forceinline__ Scene scene_view(const ptl::SceneDev& d) {
 	Scene s;
 	s.geo = (cf4)d.geo; s.mat = (cf4)d.mat; s.dirs = (cf4)d.dirs;
 	s.disc = (cf2)d.disc; s.samples = (cf2)d.samples;
-	s.cell_start = (cu32)d.cell_start; s.cell_items = (cu32)d.cell_items;
+	s.cell_start = (cu32)d.cell_start; s.cell_items = (cu32)d.cell_items; s.obj_range = (cu32)d.obj_range;
 	s.offsets = (ci32)d.offsets;
 	s.n = d.n; s.brute = d.brute; s.grid = d.grid;
 	return s;
@@ -281,41 +281,46 @@ PT_DEV void to_world(const GeoRef& g, V3 opos, bool rotated, V3& pos, V3& nrm) {
 	nrm = normalise(nrm);
 }
 
-// getIntersection (code/raycast.cpp:813-893).  p0 = plane G_POS already loaded by the caller.
-PT_DEV float intersect(const GeoRef& g, v4f p0, V3 rp, V3 rd, V3& pos, V3& nrm) {
-	v4f p3 = g.plane(G_DIM);
-	int tf = __float_as_int(p3.w);
-	int type = tf & 0xff;
-	bool rotated = (tf >> 8) & FLAG_ROTATED, even = (tf >> 8) & FLAG_EVEN;
+// Intersection kinds: the six straight-line variants getIntersection (code/raycast.cpp:813-893)
+// dispatches to.  The wave-cooperative cast bins candidates by kind so that a wavefront runs one
+// variant at a time.
+enum { KIND_SPHERE = 0, KIND_BOX = 1, KIND_BOX_ROTATED = 2, KIND_ELLIPSOID = 3, KIND_CYLINDER = 4, KIND_CONE = 5, KIND_COUNT = 6 };
+PT_DEV int kind_of(int type, bool rotated, bool even) {
+	if(type == PT_GEOM_SPHERE) return even ? KIND_SPHERE : KIND_ELLIPSOID;
+	if(type == PT_GEOM_BOX) return rotated ? KIND_BOX_ROTATED : KIND_BOX;
+	return type == PT_GEOM_CYLINDER ? KIND_CYLINDER : KIND_CONE;
+}
+
+template <int KIND>
+PT_DEV float intersect_kind(const GeoRef& g, v4f p0, v4f p3, V3 rp, V3 rd, V3& pos, V3& nrm) {
 	V3 opos = v3(p0.x, p0.y, p0.z);
 	V3 dim = v3(p3.x, p3.y, p3.z);
 	float distance = -1;
-	if(type == PT_GEOM_SPHERE && even) {
+	if(KIND == KIND_SPHERE) {
 		distance = hit_sphere(rp, rd, opos, dim.x * 0.5f, pos, nrm);
-	} else if(type == PT_GEOM_BOX) {
-		if(!rotated) {
-			distance = hit_box(rp, rd, opos, dim, pos, nrm);
-		} else {
-			v4f ri = g.plane(G_ROTINV);
-			V3 lp = rp - opos;
-			V3 le = lp + rd;
-			lp = rotate(ri, lp);
-			le = rotate(ri, le);
-			V3 ld = normalise(le - lp);
-			distance = hit_box(lp, ld, v3(0, 0, 0), dim, pos, nrm);
-			if(distance != -1) {
-				v4f r = g.plane(G_ROT);
-				pos = rotate(r, pos);
-				pos = pos + opos;
-				nrm = rotate(r, nrm);
-				distance = length(rp - pos);
-			}
+	} else if(KIND == KIND_BOX) {
+		distance = hit_box(rp, rd, opos, dim, pos, nrm);
+	} else if(KIND == KIND_BOX_ROTATED) {
+		v4f ri = g.plane(G_ROTINV);
+		V3 lp = rp - opos;
+		V3 le = lp + rd;
+		lp = rotate(ri, lp);
+		le = rotate(ri, le);
+		V3 ld = normalise(le - lp);
+		distance = hit_box(lp, ld, v3(0, 0, 0), dim, pos, nrm);
+		if(distance != -1) {
+			v4f r = g.plane(G_ROT);
+			pos = rotate(r, pos);
+			pos = pos + opos;
+			nrm = rotate(r, nrm);
+			distance = length(rp - pos);
 		}
-	} else if(type <= PT_GEOM_CONE) {
+	} else {
+		bool rotated = (__float_as_int(p3.w) >> 8) & FLAG_ROTATED;
 		V3 lp, ld;
 		to_unit(g, opos, rotated, rp, rd, lp, ld);
-		if(type == PT_GEOM_SPHERE) distance = hit_sphere(lp, ld, v3(0, 0, 0), 0.5f, pos, nrm);
-		else if(type == PT_GEOM_CYLINDER) distance = hit_cylinder(lp, ld, pos, nrm);
+		if(KIND == KIND_ELLIPSOID) distance = hit_sphere(lp, ld, v3(0, 0, 0), 0.5f, pos, nrm);
+		else if(KIND == KIND_CYLINDER) distance = hit_cylinder(lp, ld, pos, nrm);
 		else distance = hit_cone(lp, ld, pos, nrm);
 		if(distance != -1) {
 			to_world(g, opos, rotated, pos, nrm);
@@ -323,6 +328,22 @@ PT_DEV float intersect(const GeoRef& g, v4f p0, V3 rp, V3 rd, V3& pos, V3& nrm) 
 		}
 	}
 	return distance;
+}
+
+// getIntersection (code/raycast.cpp:813-893).  p0 = plane G_POS already loaded by the caller.
+PT_DEV float intersect(const GeoRef& g, v4f p0, V3 rp, V3 rd, V3& pos, V3& nrm) {
+	v4f p3 = g.plane(G_DIM);
+	int tf = __float_as_int(p3.w);
+	int type = tf & 0xff;
+	if(type > PT_GEOM_CONE) return -1;
+	switch(kind_of(type, (tf >> 8) & FLAG_ROTATED, (tf >> 8) & FLAG_EVEN)) {
+		case KIND_SPHERE: return intersect_kind<KIND_SPHERE>(g, p0, p3, rp, rd, pos, nrm);
+		case KIND_BOX: return intersect_kind<KIND_BOX>(g, p0, p3, rp, rd, pos, nrm);
+		case KIND_BOX_ROTATED: return intersect_kind<KIND_BOX_ROTATED>(g, p0, p3, rp, rd, pos, nrm);
+		case KIND_ELLIPSOID: return intersect_kind<KIND_ELLIPSOID>(g, p0, p3, rp, rd, pos, nrm);
+		case KIND_CYLINDER: return intersect_kind<KIND_CYLINDER>(g, p0, p3, rp, rd, pos, nrm);
+		default: return intersect_kind<KIND_CONE>(g, p0, p3, rp, rd, pos, nrm);
+	}
 }
 
 // ---- grid traversal (code/raycast.cpp:619-741) --------------------------------------------------
@@ -467,6 +488,209 @@ template <bool HASH>
 PT_DEV int cast(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface& surf, uint64_t& hash) {
 	if(sc.brute) return cast_all(sc, rp, rd, hpos, hnrm, surf);
 	return cast_grid<HASH>(sc, rp, rd, hpos, hnrm, surf, hash);
+}
+
+// ---- wave-cooperative grid cast ------------------------------------------------------------------
+// Same results as cast_grid, organised for wave64: the per-lane walk only COLLECTS candidates (cheap:
+// cell list reads, a duplicate check and a conservative bounding-sphere filter), the collected
+// (ray, entity) pairs of the whole wavefront are binned by intersection kind in LDS, and the
+// expensive analytic intersections then run one kind at a time with lanes taken from the bins, so a
+// wavefront executes one straight-line variant with (nearly) all lanes busy instead of the union of
+// all variants with a few.  Collection runs a segment of COOP_CELLS cells ahead of the decision
+// which cell wins; the reference's rule (first visited cell with a hit inside it; nearest hit in
+// that cell; lowest id on equal distance; code/raycast.cpp:957-983) is restored exactly by a 64-bit
+// key (cell ordinal | distance bits | id) reduced with an LDS atomic min per ray.
+constexpr int COOP_CELLS = 8;                 // cells a lane records per segment
+constexpr int COOP_BUDGET = 8;                // candidates a lane may submit per segment
+constexpr int COOP_POOL = 64 * COOP_BUDGET;
+constexpr uint64_t COOP_NONE = ~0ull;
+
+struct CoopShared {                           // one per wavefront
+	float ray[6][64];                         // origin, direction of each lane's ray
+	uint32_t cells[COOP_CELLS][64];           // packed coordinates of the cells recorded this segment
+	uint32_t ncell[64];
+	unsigned long long best[64];              // winning key per ray
+	float res[6][64];                         // hit position, normal of the winner
+	uint32_t pool[COOP_POOL];                 // submitted candidates: owner lane << 26 | kind << 23 | entity
+	uint32_t sorted[COOP_POOL];               // the same, grouped by kind
+	uint32_t count[KIND_COUNT + 2];           // per kind, [KIND_COUNT] = total
+	uint32_t fill[KIND_COUNT + 2];
+};
+
+PT_DEV void wave_sync() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+PT_DEV uint32_t pack_cell(int x, int y, int z) { return (uint32_t)x | ((uint32_t)y << 10) | ((uint32_t)z << 20); }
+PT_DEV bool range_has(uint32_t lo, uint32_t hi, uint32_t c) {
+	uint32_t cx = c & 1023, cy = (c >> 10) & 1023, cz = (c >> 20) & 1023;
+	return cx >= (lo & 1023) && cx <= (hi & 1023) && cy >= ((lo >> 10) & 1023) && cy <= ((hi >> 10) & 1023) &&
+	       cz >= ((lo >> 20) & 1023) && cz <= ((hi >> 20) & 1023);
+}
+// Conservative reject: true when the ray's line misses the entity's (slightly enlarged) bounding
+// sphere or the sphere lies wholly behind the origin.  No exact intersector can report a hit then,
+// so skipping the entity does not change any result.  No divide, no square root.
+PT_DEV bool sphere_rejects(V3 rp, V3 rd, v4f p0) {
+	V3 l = rp - v3(p0.x, p0.y, p0.z);
+	float dd = dot(rd, rd), dl = dot(rd, l), ll = dot(l, l);
+	float r = p0.w * 1.002f + 1e-3f;
+	float r2 = r * r;
+	float slack = 1e-5f * (dl * dl + dd * ll);
+	float disc = dl * dl - dd * (ll - r2);
+	bool may_hit = (disc + slack >= 0) && (dl <= 0 || ll <= r2 * 1.0001f + slack);
+	return !may_hit;
+}
+
+// One chunk of up to 64 same-kind candidates, one per lane.  Called by the whole wavefront: the
+// rendezvous between the atomic min and the winner's write-back must be reached by all 64 lanes.
+template <int KIND>
+PT_DEV void coop_chunk(const Scene& sc, CoopShared& sh, uint32_t base, uint32_t end, int lane) {
+	uint32_t i = base + (uint32_t)lane;
+	unsigned long long key = COOP_NONE;
+	int owner = 0;
+	V3 pos = v3(0, 0, 0), nrm = v3(0, 0, 0);
+	if(i < end) {
+		uint32_t entry = sh.sorted[i];
+		owner = (int)(entry >> 26);
+		int id = (int)(entry & 0x7fffffu);
+		V3 rp = v3(sh.ray[0][owner], sh.ray[1][owner], sh.ray[2][owner]);
+		V3 rd = v3(sh.ray[3][owner], sh.ray[4][owner], sh.ray[5][owner]);
+		GeoRef g = { sc.geo, sc.n, id };
+		v4f p0 = g.plane(G_POS), p3 = g.plane(G_DIM);
+		float distance = intersect_kind<KIND>(g, p0, p3, rp, rd, pos, nrm);
+		if(distance > 0) {
+			uint32_t lo = sc.obj_range[2 * id], hi = sc.obj_range[2 * id + 1];
+			int n = (int)sh.ncell[owner];
+			for(int o = 0; o < n; o++) {
+				uint32_t c = sh.cells[o][owner];
+				if(!range_has(lo, hi, c)) continue;
+				int cx = (int)(c & 1023), cy = (int)((c >> 10) & 1023), cz = (int)((c >> 20) & 1023);
+				V3 blo = v3((float)((cx + sc.grid.cmin[0]) * sc.grid.cs[0]), (float)((cy + sc.grid.cmin[1]) * sc.grid.cs[1]), (float)((cz + sc.grid.cmin[2]) * sc.grid.cs[2]));
+				V3 bhi = v3((float)((cx + 1 + sc.grid.cmin[0]) * sc.grid.cs[0]), (float)((cy + 1 + sc.grid.cmin[1]) * sc.grid.cs[1]), (float)((cz + 1 + sc.grid.cmin[2]) * sc.grid.cs[2]));
+				if(inside_box(pos, blo, bhi)) {
+					key = ((unsigned long long)o << 55) | ((unsigned long long)__float_as_uint(distance) << 23) | (unsigned long long)id;
+					break;
+				}
+			}
+		}
+		if(key != COOP_NONE) atomicMin(&sh.best[owner], key);
+	}
+	wave_sync();
+	if(key != COOP_NONE && sh.best[owner] == key) {
+		sh.res[0][owner] = pos.x; sh.res[1][owner] = pos.y; sh.res[2][owner] = pos.z;
+		sh.res[3][owner] = nrm.x; sh.res[4][owner] = nrm.y; sh.res[5][owner] = nrm.z;
+	}
+}
+
+// All 64 lanes must call this together; `active` lanes own a ray, the others only lend a hand.
+PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface& surf) {
+	Walk w;
+	bool walking = false;
+	if(active) {
+		V3 start;
+		if(grid_entry(sc.grid, rp, rd, start)) { walk_start(sc.grid, start, rd, w); walking = true; }
+		sh.ray[0][lane] = rp.x; sh.ray[1][lane] = rp.y; sh.ray[2][lane] = rp.z;
+		sh.ray[3][lane] = rd.x; sh.ray[4][lane] = rd.y; sh.ray[5][lane] = rd.z;
+	}
+	int result = 0;
+	int k_resume = -1;
+	unsigned long long carry = COOP_NONE;          // best hit so far in a cell that is only partly submitted
+	V3 carry_pos = v3(0, 0, 0), carry_nrm = v3(0, 0, 0);
+
+	while(__ballot(walking) != 0) {
+		// ---- reset the wavefront's bins --------------------------------------------------------
+		if(lane < KIND_COUNT + 2) { sh.count[lane] = 0; sh.fill[lane] = 0; }
+		sh.best[lane] = carry;
+		if(carry != COOP_NONE) {
+			sh.res[0][lane] = carry_pos.x; sh.res[1][lane] = carry_pos.y; sh.res[2][lane] = carry_pos.z;
+			sh.res[3][lane] = carry_nrm.x; sh.res[4][lane] = carry_nrm.y; sh.res[5][lane] = carry_nrm.z;
+		}
+		sh.ncell[lane] = 0;
+		wave_sync();
+
+		// ---- phase 1: every walking lane collects candidates along its ray -----------------------
+		int recorded = 0;
+		bool partial = false;
+		if(walking) {
+			int submitted = 0;
+			uint32_t prev = 0xffffffffu;
+			for(;;) {
+				int cell = w.cz * sc.grid.cnt[1] * sc.grid.cnt[0] + w.cy * sc.grid.cnt[0] + w.cx;
+				uint32_t k0 = sc.cell_start[cell], k1 = sc.cell_start[cell + 1];
+				const bool resumed = k_resume >= 0;
+				if(resumed) k0 = (uint32_t)k_resume;
+				uint32_t here = pack_cell(w.cx, w.cy, w.cz);
+				sh.cells[recorded][lane] = here;
+				recorded++;
+				for(uint32_t k = k0; k < k1; k++) {
+					int id = (int)sc.cell_items[k];
+					uint32_t lo = sc.obj_range[2 * id], hi = sc.obj_range[2 * id + 1];
+					if(prev != 0xffffffffu && range_has(lo, hi, prev)) continue;     // submitted one cell earlier
+					v4f p0 = sc.geo[(size_t)G_POS * sc.n + id];
+					if(sphere_rejects(rp, rd, p0)) continue;
+					if(submitted == COOP_BUDGET) { partial = true; k_resume = (int)k; break; }
+					uint32_t kind = (lo >> 30) | ((hi >> 30) << 2);
+					uint32_t slot = atomicAdd(&sh.count[KIND_COUNT], 1u);
+					atomicAdd(&sh.count[kind], 1u);
+					sh.pool[slot] = ((uint32_t)lane << 26) | (kind << 23) | (uint32_t)id;
+					submitted++;
+				}
+				if(partial) break;
+				k_resume = -1;
+				// entities of a cell that was only partly submitted in THIS segment (its head went
+				// into the previous one) must not be treated as already submitted by the next cell
+				prev = resumed ? 0xffffffffu : here;
+				if(!walk_next(sc.grid, w)) { walking = false; break; }
+				if(recorded == COOP_CELLS) break;
+			}
+			sh.ncell[lane] = (uint32_t)recorded;
+		}
+		wave_sync();
+
+		// ---- phase 2: group the submissions by kind, then intersect one kind at a time -----------
+		uint32_t off[KIND_COUNT + 1];
+		off[0] = 0;
+		#pragma unroll
+		for(int k = 0; k < KIND_COUNT; k++) off[k + 1] = off[k] + sh.count[k];
+		uint32_t total = off[KIND_COUNT];
+		for(uint32_t i = (uint32_t)lane; i < total; i += 64) {
+			uint32_t e = sh.pool[i];
+			uint32_t kind = (e >> 23) & 7u;
+			uint32_t base = kind == 0 ? off[0] : kind == 1 ? off[1] : kind == 2 ? off[2] : kind == 3 ? off[3] : kind == 4 ? off[4] : off[5];
+			sh.sorted[base + atomicAdd(&sh.fill[kind], 1u)] = e;
+		}
+		wave_sync();
+		for(uint32_t base = off[0]; base < off[1]; base += 64) coop_chunk<KIND_SPHERE>(sc, sh, base, off[1], lane);
+		for(uint32_t base = off[1]; base < off[2]; base += 64) coop_chunk<KIND_BOX>(sc, sh, base, off[2], lane);
+		for(uint32_t base = off[2]; base < off[3]; base += 64) coop_chunk<KIND_BOX_ROTATED>(sc, sh, base, off[3], lane);
+		for(uint32_t base = off[3]; base < off[4]; base += 64) coop_chunk<KIND_ELLIPSOID>(sc, sh, base, off[4], lane);
+		for(uint32_t base = off[4]; base < off[5]; base += 64) coop_chunk<KIND_CYLINDER>(sc, sh, base, off[5], lane);
+		for(uint32_t base = off[5]; base < off[6]; base += 64) coop_chunk<KIND_CONE>(sc, sh, base, off[6], lane);
+		wave_sync();
+
+		// ---- phase 3: each owner reads its verdict -----------------------------------------------
+		if(active && result == 0 && recorded > 0) {
+			unsigned long long key = sh.best[lane];
+			if(key != COOP_NONE) {
+				int ord = (int)(key >> 55);
+				V3 p = v3(sh.res[0][lane], sh.res[1][lane], sh.res[2][lane]);
+				V3 q = v3(sh.res[3][lane], sh.res[4][lane], sh.res[5][lane]);
+				if(partial && ord == recorded - 1) {
+					// the best hit lies in the cell whose list is not exhausted yet: keep it, go on with that cell
+					carry = key & ((1ull << 55) - 1);
+					carry_pos = p; carry_nrm = q;
+				} else {
+					result = (int)(key & 0x7fffffu) + 1;
+					hpos = p; hnrm = q;
+					walking = false;
+					carry = COOP_NONE;
+				}
+			}
+		}
+	}
+	if(result != 0) surf = surface_of(sc, result - 1);
+	return result;
 }
 
 // ---- optics (code/raycast.cpp:194-242) -----------------------------------------------------------

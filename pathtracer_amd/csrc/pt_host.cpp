@@ -337,4 +337,30 @@ bool build_grid(const float* records, int n, int hint, GridDesc* g, std::vector<
 	return true;
 }
 
+bool object_ranges(const float* records, int n, const GridDesc& g, std::vector<uint32_t>* ranges) {
+	ranges->assign((size_t)(n > 0 ? n : 1) * 2, 0);
+	if(g.cell_count[0] > 1023 || g.cell_count[1] > 1023 || g.cell_count[2] > 1023 || n >= (1 << 23)) return false;
+	for(int i = 0; i < n; i++) {
+		const float* r = records + (size_t)i * PT_F_STRIDE;
+		uint32_t a[3], b[3];
+		for(int k = 0; k < 3; k++) {   // the same range the grid build uses (code/app.cpp:1297-1312)
+			float half = r[PT_F_BBOX + k] / 2;
+			float mn = r[PT_F_POS + k] - half, mx = r[PT_F_POS + k] + half;
+			int lo = (int)(mn / g.cell_size[k]) - g.coord_min[k];
+			if(mn < 0) lo--;
+			int hi = (int)(mx / g.cell_size[k]) - g.coord_min[k];
+			if(mx < 0) hi--;
+			a[k] = (uint32_t)clamp_cell(lo, g.cell_count[k] - 1);
+			b[k] = (uint32_t)clamp_cell(hi, g.cell_count[k] - 1);
+		}
+		int32_t type, flags;
+		memcpy(&type, r + PT_F_TYPE, 4);
+		memcpy(&flags, r + PT_F_FLAGS, 4);
+		uint32_t kind = type == PT_GEOM_SPHERE ? ((flags & 2) ? 0u : 3u) : type == PT_GEOM_BOX ? ((flags & 1) ? 2u : 1u) : type == PT_GEOM_CYLINDER ? 4u : 5u;
+		(*ranges)[(size_t)i * 2] = a[0] | (a[1] << 10) | (a[2] << 20) | ((kind & 3u) << 30);
+		(*ranges)[(size_t)i * 2 + 1] = b[0] | (b[1] << 10) | (b[2] << 20) | ((kind >> 2) << 30);
+	}
+	return true;
+}
+
 }  // namespace pt

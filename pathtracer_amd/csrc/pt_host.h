@@ -45,4 +45,8 @@ void make_samples(Pcg& rng, int spp_wanted, int grid_width, std::vector<f2>* sam
 bool build_grid(const float* records, int n, int hint, GridDesc* g, std::vector<uint32_t>* cell_start,
                 std::vector<uint32_t>* cell_items);
 
+// Per entity two words: its inclusive cell range (10 bits per axis, low word = lower corner) and its
+// intersection kind (3 bits split over the two spare bit pairs).  False when a range does not fit.
+bool object_ranges(const float* records, int n, const GridDesc& g, std::vector<uint32_t>* ranges);
+
 }  // namespace pt

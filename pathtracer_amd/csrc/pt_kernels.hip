@@ -9,6 +9,8 @@
 // live rays stay compacted in the 64 lanes between bounces without ever going through memory.
 // Per-pixel sums are kept in registers in sample order, so the image is a pure function of the
 // inputs: independent of wave scheduling, grid size and GPU count.
+#include <cstdlib>
+
 #include "pt_device.h"
 
 using namespace ptd;
@@ -29,10 +31,14 @@ __device__ __forceinline__ int lanes_below(uint64_t mask) {
 // Lane states of the trace loop.
 enum { NEED_PIXEL = 0, NEED_PATH = 1, IN_FLIGHT = 2, RETIRED = 3 };
 
-// BRUTE selects the cast at compile time (castRayAll for scenes under the brute-force threshold,
-// the grid walk otherwise) so that the small-scene kernel does not carry the DDA's registers.
-template <bool BRUTE>
+// MODE selects the cast at compile time so that each variant carries only its own registers:
+// castRayAll for scenes under the brute-force threshold, the per-lane grid walk, or the
+// wave-cooperative grid walk (kind-binned intersections through LDS).
+enum { CAST_BRUTE = 0, CAST_GRID_LANE = 1, CAST_GRID_COOP = 2 };
+template <int MODE>
 __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(ptl::TraceJob job) {
+	__shared__ __attribute__((aligned(16))) char lds_raw[MODE == CAST_GRID_COOP ? sizeof(CoopShared) * (kBlock / 64) : 16];
+	CoopShared& coop = reinterpret_cast<CoopShared*>(lds_raw)[MODE == CAST_GRID_COOP ? threadIdx.x / 64 : 0];
 	const Scene sc = scene_view(job.scene);
 	const FrameRef fr = (FrameRef)job.frame;
 	const int lane = lane_id();
@@ -118,12 +124,18 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 		}
 
 		// ---- stage 2+3: extend one ray and shade the hit (code/raycast.cpp:1092-1261) ---------
-		if(state == IN_FLIGHT) {
-			V3 hp = v3(0, 0, 0), hn = v3(0, 0, 0);
-			Surface surf;
-			surf.m0 = (v4f)(0.0f); surf.m1 = (v4f){ 0.0f, 0.0f, 0.0f, 1.0f }; surf.rough = 0;
+		const bool flying = state == IN_FLIGHT;
+		V3 hp = v3(0, 0, 0), hn = v3(0, 0, 0);
+		Surface surf;
+		surf.m0 = (v4f)(0.0f); surf.m1 = (v4f){ 0.0f, 0.0f, 0.0f, 1.0f }; surf.rough = 0;
+		int id = 0;
+		if(MODE == CAST_GRID_COOP) {
+			id = cast_grid_coop(sc, coop, lane, flying, rp, rd, hp, hn, surf);   // the whole wavefront takes part
+		} else if(flying) {
 			uint64_t unused = 0;
-			int id = BRUTE ? cast_all(sc, rp, rd, hp, hn, surf) : cast_grid<false>(sc, rp, rd, hp, hn, surf, unused);
+			id = MODE == CAST_BRUTE ? cast_all(sc, rp, rd, hp, hn, surf) : cast_grid<false>(sc, rp, rd, hp, hn, surf, unused);
+		}
+		if(flying) {
 			casts++;
 			bool alive = shade(sc, fr, id, surf, hp, hn, bounce, rp, rd, att, col, rng);
 			bounce++;
@@ -232,9 +244,10 @@ namespace ptl {
 const char* trace_kernel_name() { return "pt_k_trace"; }
 
 hipError_t launch_trace(const TraceJob& job, hipStream_t stream, int* grid_blocks_out) {
-	static int blocks_per_cu[2] = { 0, 0 }, cus = 0;
-	const int which = job.scene.brute ? 1 : 0;
-	if(blocks_per_cu[which] == 0) {
+	static int blocks_per_cu[3] = { 0, 0, 0 }, cus = 0;
+	static const bool lane_walk = getenv("PT_GRID_PER_LANE") != nullptr;     // A/B switch: per-lane grid walk
+	const int mode = job.scene.brute ? CAST_BRUTE : (job.scene.coop && !lane_walk ? CAST_GRID_COOP : CAST_GRID_LANE);
+	if(blocks_per_cu[mode] == 0) {
 		int dev = 0;
 		hipError_t e = hipGetDevice(&dev);
 		if(e != hipSuccess) return e;
@@ -243,21 +256,23 @@ hipError_t launch_trace(const TraceJob& job, hipStream_t stream, int* grid_block
 		if(e != hipSuccess) return e;
 		cus = prop.multiProcessorCount;
 		int b = 0;
-		e = which ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, pt_k_trace<true>, kBlock, 0)
-		          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, pt_k_trace<false>, kBlock, 0);
+		e = mode == CAST_BRUTE ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, pt_k_trace<CAST_BRUTE>, kBlock, 0)
+		  : mode == CAST_GRID_LANE ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, pt_k_trace<CAST_GRID_LANE>, kBlock, 0)
+		  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, pt_k_trace<CAST_GRID_COOP>, kBlock, 0);
 		if(e != hipSuccess) return e;
-		blocks_per_cu[which] = b > 0 ? b : 1;
+		blocks_per_cu[mode] = b > 0 ? b : 1;
 	}
 	hipError_t e = hipMemsetAsync(job.group_counter, 0, sizeof(uint32_t), stream);
 	if(e != hipSuccess) return e;
 	// persistent launch: every resident wave pulls 64-pixel tiles until the partition is drained
 	long blocks = ((long)job.n_groups + 3) / 4;
-	long resident = (long)cus * blocks_per_cu[which];
+	long resident = (long)cus * blocks_per_cu[mode];
 	if(blocks > resident) blocks = resident;
 	if(blocks < 1) blocks = 1;
 	if(grid_blocks_out) *grid_blocks_out = (int)blocks;
-	if(which) hipLaunchKernelGGL(pt_k_trace<true>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
-	else hipLaunchKernelGGL(pt_k_trace<false>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
+	if(mode == CAST_BRUTE) hipLaunchKernelGGL(pt_k_trace<CAST_BRUTE>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
+	else if(mode == CAST_GRID_LANE) hipLaunchKernelGGL(pt_k_trace<CAST_GRID_LANE>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
+	else hipLaunchKernelGGL(pt_k_trace<CAST_GRID_COOP>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
 	return hipGetLastError();
 }
 

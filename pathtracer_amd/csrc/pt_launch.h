@@ -16,12 +16,14 @@ struct SceneDev {
 	const float4* mat;
 	const uint32_t* cell_start;
 	const uint32_t* cell_items;
+	const uint32_t* obj_range;  // per entity: inclusive cell range, 10 bits per axis, and its intersection kind (2 words)
 	const float4* dirs;
 	const float2* disc;
 	const float2* samples;
 	const int32_t* offsets;     // tile_w^2 + 1 sample offsets
 	int n;
 	int brute;
+	int coop;                   // 1: the wave-cooperative cast may be used (ranges fit their packing)
 	GridDev grid;
 };
 
