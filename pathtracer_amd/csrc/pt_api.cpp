@@ -626,6 +626,14 @@ int pt_assemble(pt_ctx* c, const float* d_parts, size_t stride_floats, int part_
 	return PT_OK;
 }
 
+/* Diagnostic builds only: event counters of the cooperative cast (0 values otherwise). */
+int pt_debug_coop_stats(pt_ctx* c, unsigned long long* out16) {
+	if(!c || !out16) return PT_ERR_ARG;
+	PT_HIP(c, hipSetDevice(c->device));
+	PT_HIP(c, hipDeviceSynchronize());
+	return ptl::coop_stats(out16);
+}
+
 int pt_partition_tiles(int width, int height, int part_index, int part_count) {
 	if(width < 1 || height < 1 || part_count < 1 || part_index < 0 || part_index >= part_count) return PT_ERR_ARG;
 	int tiles = ((width + 7) / 8) * ((height + 7) / 8);

@@ -412,6 +412,28 @@ PT_DEV bool walk_next(const Grid& g, Walk& w) {
 	return true;
 }
 
+// The walker without the cell box: the cooperative cast re-derives a cell's box from its
+// coordinates, which gives the same floats (both are (coord + coordMin [+ 1]) * cellSize converted).
+struct WalkLite { int cx, cy, cz, sx, sy, sz; float tx, ty, tz, dx, dy, dz; };
+PT_DEV WalkLite lite_of(const Walk& w) {
+	WalkLite l;
+	l.cx = w.cx; l.cy = w.cy; l.cz = w.cz; l.sx = w.sx; l.sy = w.sy; l.sz = w.sz;
+	l.tx = w.tx; l.ty = w.ty; l.tz = w.tz; l.dx = w.dx; l.dy = w.dy; l.dz = w.dz;
+	return l;
+}
+#define PT_LITE_STEP(C, S, T, DT, CNT) { C += S; if(C < 0 || C >= CNT) return false; T += DT; }
+PT_DEV bool lite_next(const Grid& g, WalkLite& w) {
+	if(w.tx < w.ty) {
+		if(w.tx < w.tz) PT_LITE_STEP(w.cx, w.sx, w.tx, w.dx, g.cnt[0])
+		else PT_LITE_STEP(w.cz, w.sz, w.tz, w.dz, g.cnt[2])
+	} else {
+		if(w.ty < w.tz) PT_LITE_STEP(w.cy, w.sy, w.ty, w.dy, g.cnt[1])
+		else PT_LITE_STEP(w.cz, w.sz, w.tz, w.dz, g.cnt[2])
+	}
+	return true;
+}
+PT_DEV int lite_cell(const Grid& g, const WalkLite& w) { return w.cz * g.cnt[1] * g.cnt[0] + w.cy * g.cnt[0] + w.cx; }
+
 #define PT_HASH_INIT 1469598103934665603ULL
 PT_DEV uint64_t hash_cell(uint64_t h, int index) { return (h ^ (uint64_t)(uint32_t)(index + 1)) * 1099511628211ULL; }
 
@@ -500,9 +522,23 @@ PT_DEV int cast(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface& surf
 // which cell wins; the reference's rule (first visited cell with a hit inside it; nearest hit in
 // that cell; lowest id on equal distance; code/raycast.cpp:957-983) is restored exactly by a 64-bit
 // key (cell ordinal | distance bits | id) reduced with an LDS atomic min per ray.
-constexpr int COOP_CELLS = 8;                 // cells a lane records per segment
-constexpr int COOP_BUDGET = 8;                // candidates a lane may submit per segment
+#ifndef PT_COOP_CELLS
+#define PT_COOP_CELLS 8
+#endif
+#ifndef PT_COOP_BUDGET
+#define PT_COOP_BUDGET 8
+#endif
+constexpr int COOP_CELLS = PT_COOP_CELLS;     // cells a lane records per segment
+constexpr int COOP_BUDGET = PT_COOP_BUDGET;   // candidates a lane may submit per segment
 constexpr int COOP_POOL = 64 * COOP_BUDGET;
+#ifndef PT_COOP_LOOK
+#define PT_COOP_LOOK 1
+#endif
+#ifndef PT_COOP_MIN_WALKING
+#define PT_COOP_MIN_WALKING 56
+#endif
+constexpr int COOP_MIN_WALKING = PT_COOP_MIN_WALKING;   // fewer walking lanes than this: return and refill
+constexpr int COOP_LOOK = PT_COOP_LOOK;        // cells whose list bounds are fetched ahead in one go
 constexpr uint64_t COOP_NONE = ~0ull;
 
 struct CoopShared {                           // one per wavefront
@@ -517,6 +553,12 @@ struct CoopShared {                           // one per wavefront
 	uint32_t fill[KIND_COUNT + 2];
 };
 
+#ifdef PT_COOP_STATS
+#define PT_STAT(i, v) atomicAdd((unsigned long long*)&g_coop_stats[i], (unsigned long long)(v))
+__device__ unsigned long long g_coop_stats[16];
+#else
+#define PT_STAT(i, v)
+#endif
 PT_DEV void wave_sync() {
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
@@ -549,6 +591,8 @@ PT_DEV void coop_chunk(const Scene& sc, CoopShared& sh, uint32_t base, uint32_t 
 	uint32_t i = base + (uint32_t)lane;
 	unsigned long long key = COOP_NONE;
 	int owner = 0;
+	if(lane == 0) PT_STAT(2, 1);
+	if(i < end) PT_STAT(3, 1);
 	V3 pos = v3(0, 0, 0), nrm = v3(0, 0, 0);
 	if(i < end) {
 		uint32_t entry = sh.sorted[i];
@@ -574,7 +618,7 @@ PT_DEV void coop_chunk(const Scene& sc, CoopShared& sh, uint32_t base, uint32_t 
 				}
 			}
 		}
-		if(key != COOP_NONE) atomicMin(&sh.best[owner], key);
+		if(key != COOP_NONE) { atomicMin(&sh.best[owner], key); PT_STAT(8, 1); }
 	}
 	wave_sync();
 	if(key != COOP_NONE && sh.best[owner] == key) {
@@ -583,68 +627,108 @@ PT_DEV void coop_chunk(const Scene& sc, CoopShared& sh, uint32_t base, uint32_t 
 	}
 }
 
+// What a lane keeps of a cast between calls: the walker, the resume point inside a partly submitted
+// cell and the best hit found in that cell so far (its position and normal stay in CoopShared::res).
+struct CoopLane {
+	WalkLite w;
+	int k_resume;
+	unsigned long long carry;
+	bool walking;
+};
+PT_DEV void coop_lane_reset(CoopLane& st) { st.k_resume = -1; st.carry = COOP_NONE; st.walking = false; }
+
 // All 64 lanes must call this together; `active` lanes own a ray, the others only lend a hand.
-PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface& surf) {
-	Walk w;
-	bool walking = false;
-	if(active) {
+// A lane with `fresh` set starts the cast of (rp, rd); an active lane without it continues the cast
+// it was in.  The call returns as soon as fewer than COOP_MIN_WALKING lanes are still walking, so
+// the caller can shade the finished rays and hand their lanes new ones instead of idling them until
+// the longest walk of the wavefront ends; `done` tells which lanes have their result.
+PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active, bool fresh, CoopLane& st, V3 rp, V3 rd, V3& hpos,
+                          V3& hnrm, Surface& surf, bool& done) {
+	if(active && fresh) {
+		coop_lane_reset(st);
 		V3 start;
-		if(grid_entry(sc.grid, rp, rd, start)) { walk_start(sc.grid, start, rd, w); walking = true; }
+		if(grid_entry(sc.grid, rp, rd, start)) {
+			Walk full;
+			walk_start(sc.grid, start, rd, full);
+			st.w = lite_of(full);
+			st.walking = true;
+		}
 		sh.ray[0][lane] = rp.x; sh.ray[1][lane] = rp.y; sh.ray[2][lane] = rp.z;
 		sh.ray[3][lane] = rd.x; sh.ray[4][lane] = rd.y; sh.ray[5][lane] = rd.z;
 	}
+	bool walking = active && st.walking;
 	int result = 0;
-	int k_resume = -1;
-	unsigned long long carry = COOP_NONE;          // best hit so far in a cell that is only partly submitted
-	V3 carry_pos = v3(0, 0, 0), carry_nrm = v3(0, 0, 0);
 
+	if(lane == 0 && __ballot(walking) != 0) PT_STAT(9, 1);
 	while(__ballot(walking) != 0) {
+		if(lane == 0) PT_STAT(1, 1);
 		// ---- reset the wavefront's bins --------------------------------------------------------
 		if(lane < KIND_COUNT + 2) { sh.count[lane] = 0; sh.fill[lane] = 0; }
-		sh.best[lane] = carry;
-		if(carry != COOP_NONE) {
-			sh.res[0][lane] = carry_pos.x; sh.res[1][lane] = carry_pos.y; sh.res[2][lane] = carry_pos.z;
-			sh.res[3][lane] = carry_nrm.x; sh.res[4][lane] = carry_nrm.y; sh.res[5][lane] = carry_nrm.z;
-		}
+		sh.best[lane] = walking ? st.carry : COOP_NONE;    // a carried hit keeps its position and normal in sh.res
 		sh.ncell[lane] = 0;
 		wave_sync();
 
 		// ---- phase 1: every walking lane collects candidates along its ray -----------------------
+		// The cell-list bounds of the next COOP_LOOK cells are fetched together (a probe copy of the
+		// walker runs ahead), so a run of empty cells costs one memory round trip, not one per cell.
 		int recorded = 0;
 		bool partial = false;
 		if(walking) {
 			int submitted = 0;
 			uint32_t prev = 0xffffffffu;
-			for(;;) {
-				int cell = w.cz * sc.grid.cnt[1] * sc.grid.cnt[0] + w.cy * sc.grid.cnt[0] + w.cx;
-				uint32_t k0 = sc.cell_start[cell], k1 = sc.cell_start[cell + 1];
-				const bool resumed = k_resume >= 0;
-				if(resumed) k0 = (uint32_t)k_resume;
-				uint32_t here = pack_cell(w.cx, w.cy, w.cz);
-				sh.cells[recorded][lane] = here;
-				recorded++;
-				for(uint32_t k = k0; k < k1; k++) {
-					int id = (int)sc.cell_items[k];
-					uint32_t lo = sc.obj_range[2 * id], hi = sc.obj_range[2 * id + 1];
-					if(prev != 0xffffffffu && range_has(lo, hi, prev)) continue;     // submitted one cell earlier
-					v4f p0 = sc.geo[(size_t)G_POS * sc.n + id];
-					if(sphere_rejects(rp, rd, p0)) continue;
-					if(submitted == COOP_BUDGET) { partial = true; k_resume = (int)k; break; }
-					uint32_t kind = (lo >> 30) | ((hi >> 30) << 2);
-					uint32_t slot = atomicAdd(&sh.count[KIND_COUNT], 1u);
-					atomicAdd(&sh.count[kind], 1u);
-					sh.pool[slot] = ((uint32_t)lane << 26) | (kind << 23) | (uint32_t)id;
-					submitted++;
+			bool stop = false;
+			while(!stop) {
+				int pc[COOP_LOOK];
+				uint32_t ka[COOP_LOOK], kb[COOP_LOOK];
+				int m = 0;
+				{
+					WalkLite probe = st.w;
+					bool more = true;
+					#pragma unroll
+					for(int j = 0; j < COOP_LOOK; j++) {
+						pc[j] = 0;
+						if(more) { pc[j] = lite_cell(sc.grid, probe); m = j + 1; if(j + 1 < COOP_LOOK) more = lite_next(sc.grid, probe); }
+					}
+					#pragma unroll
+					for(int j = 0; j < COOP_LOOK; j++) { ka[j] = sc.cell_start[pc[j]]; kb[j] = sc.cell_start[pc[j] + 1]; }
 				}
-				if(partial) break;
-				k_resume = -1;
-				// entities of a cell that was only partly submitted in THIS segment (its head went
-				// into the previous one) must not be treated as already submitted by the next cell
-				prev = resumed ? 0xffffffffu : here;
-				if(!walk_next(sc.grid, w)) { walking = false; break; }
-				if(recorded == COOP_CELLS) break;
+				#pragma unroll
+				for(int j = 0; j < COOP_LOOK; j++) {
+					if(j < m && !stop) {
+						uint32_t k0 = ka[j], k1 = kb[j];
+						const bool resumed = st.k_resume >= 0;
+						if(resumed) k0 = (uint32_t)st.k_resume;
+						uint32_t here = pack_cell(st.w.cx, st.w.cy, st.w.cz);
+						sh.cells[recorded][lane] = here;
+						recorded++;
+						for(uint32_t k = k0; k < k1; k++) {
+							int id = (int)sc.cell_items[k];
+							PT_STAT(5, 1);
+							uint32_t lo = sc.obj_range[2 * id], hi = sc.obj_range[2 * id + 1];
+							if(prev != 0xffffffffu && range_has(lo, hi, prev)) { PT_STAT(6, 1); continue; }     // submitted one cell earlier
+							v4f p0 = sc.geo[(size_t)G_POS * sc.n + id];
+							if(sphere_rejects(rp, rd, p0)) { PT_STAT(7, 1); continue; }
+							if(submitted == COOP_BUDGET) { partial = true; st.k_resume = (int)k; break; }
+							uint32_t kind = (lo >> 30) | ((hi >> 30) << 2);
+							uint32_t slot = atomicAdd(&sh.count[KIND_COUNT], 1u);
+							atomicAdd(&sh.count[kind], 1u);
+							sh.pool[slot] = ((uint32_t)lane << 26) | (kind << 23) | (uint32_t)id;
+							submitted++;
+						}
+						if(partial) { stop = true; }
+						else {
+							st.k_resume = -1;
+							// entities of a cell that was only partly submitted in THIS segment (its head went
+							// into the previous one) must not be treated as already submitted by the next cell
+							prev = resumed ? 0xffffffffu : here;
+							if(!lite_next(sc.grid, st.w)) { walking = false; stop = true; }
+							else if(recorded == COOP_CELLS) stop = true;
+						}
+					}
+				}
 			}
 			sh.ncell[lane] = (uint32_t)recorded;
+			PT_STAT(4, recorded);
 		}
 		wave_sync();
 
@@ -670,25 +754,26 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 		wave_sync();
 
 		// ---- phase 3: each owner reads its verdict -----------------------------------------------
-		if(active && result == 0 && recorded > 0) {
+		if(recorded > 0) {
 			unsigned long long key = sh.best[lane];
 			if(key != COOP_NONE) {
 				int ord = (int)(key >> 55);
-				V3 p = v3(sh.res[0][lane], sh.res[1][lane], sh.res[2][lane]);
-				V3 q = v3(sh.res[3][lane], sh.res[4][lane], sh.res[5][lane]);
 				if(partial && ord == recorded - 1) {
 					// the best hit lies in the cell whose list is not exhausted yet: keep it, go on with that cell
-					carry = key & ((1ull << 55) - 1);
-					carry_pos = p; carry_nrm = q;
+					st.carry = key & ((1ull << 55) - 1);
 				} else {
 					result = (int)(key & 0x7fffffu) + 1;
-					hpos = p; hnrm = q;
+					hpos = v3(sh.res[0][lane], sh.res[1][lane], sh.res[2][lane]);
+					hnrm = v3(sh.res[3][lane], sh.res[4][lane], sh.res[5][lane]);
 					walking = false;
-					carry = COOP_NONE;
+					st.carry = COOP_NONE;
 				}
 			}
 		}
+		if(__popcll(__ballot(walking)) < COOP_MIN_WALKING) break;
 	}
+	st.walking = walking;
+	done = active && !walking;
 	if(result != 0) surf = surface_of(sc, result - 1);
 	return result;
 }

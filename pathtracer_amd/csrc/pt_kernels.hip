@@ -59,6 +59,10 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 	int bounce = 0;
 	Rng rng = { 0, 1 };
 	uint32_t casts = 0;
+	// cooperative cast only: what a lane keeps of an unfinished cast, and whether its ray is new
+	CoopLane walk_state;
+	coop_lane_reset(walk_state);
+	bool fresh = true;
 
 	for(;;) {
 		// ---- stage 0: lanes without a pixel draw one from the wave's pool -------------------
@@ -129,13 +133,16 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 		Surface surf;
 		surf.m0 = (v4f)(0.0f); surf.m1 = (v4f){ 0.0f, 0.0f, 0.0f, 1.0f }; surf.rough = 0;
 		int id = 0;
+		bool landed = flying;
 		if(MODE == CAST_GRID_COOP) {
-			id = cast_grid_coop(sc, coop, lane, flying, rp, rd, hp, hn, surf);   // the whole wavefront takes part
+			// the whole wavefront takes part; lanes whose walk is not over yet stay in flight and resume
+			id = cast_grid_coop(sc, coop, lane, flying, fresh, walk_state, rp, rd, hp, hn, surf, landed);
+			fresh = landed || !flying;
 		} else if(flying) {
 			uint64_t unused = 0;
 			id = MODE == CAST_BRUTE ? cast_all(sc, rp, rd, hp, hn, surf) : cast_grid<false>(sc, rp, rd, hp, hn, surf, unused);
 		}
-		if(flying) {
+		if(landed) {
 			casts++;
 			bool alive = shade(sc, fr, id, surf, hp, hn, bounce, rp, rd, att, col, rng);
 			bounce++;
@@ -242,6 +249,19 @@ __global__ __launch_bounds__(kBlock) void pt_k_assemble(const float* parts, size
 namespace ptl {
 
 const char* trace_kernel_name() { return "pt_k_trace"; }
+
+// Diagnostic build only (-DPT_COOP_STATS): copies and clears the cooperative cast's event counters.
+int coop_stats(unsigned long long* out16) {
+#ifdef PT_COOP_STATS
+	unsigned long long zero[16] = { 0 };
+	if(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_coop_stats), sizeof zero) != hipSuccess) return -1;
+	if(hipMemcpyToSymbol(HIP_SYMBOL(g_coop_stats), zero, sizeof zero) != hipSuccess) return -1;
+	return 16;
+#else
+	(void)out16;
+	return 0;
+#endif
+}
 
 hipError_t launch_trace(const TraceJob& job, hipStream_t stream, int* grid_blocks_out) {
 	static int blocks_per_cu[3] = { 0, 0, 0 }, cus = 0;

@@ -61,5 +61,6 @@ hipError_t launch_srgb8(const float* rgb, size_t n, uint8_t* out, hipStream_t st
 // Tile-major partition buffers (part_count of them, each `stride` floats apart) -> row-major image.
 hipError_t launch_assemble(const float* parts, size_t stride, int part_count, int width, int height, float* rgb, hipStream_t stream);
 const char* trace_kernel_name();
+int coop_stats(unsigned long long* out16);
 
 }  // namespace ptl

@@ -1,0 +1,25 @@
+"""Diagnostic: event counters of the wave-cooperative cast (needs a library built with -DPT_COOP_STATS)."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from pathtracer_amd import api  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "glass-1080p-16spp-d32"
+world, objs, kw = bench.workload(name)
+st = api.default_settings(kw.pop("width"), kw.pop("height"), kw.pop("spp"), kw.pop("bounces"), **kw)
+r = api.Renderer(0)
+r.prepare(world, objs, st)
+buf = (C.c_ulonglong * 16)()
+r.lib.pt_debug_coop_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+r.lib.pt_debug_coop_stats(r.ctx, buf)
+r.trace()
+r.lib.pt_debug_coop_stats(r.ctx, buf)
+s = r.stats()
+names = ["", "segments", "chunks", "tests", "cells", "items", "deduped", "sphere_rejected", "accepted", "wave_casts"]
+casts = s.rays
+print(name, "casts", casts, "kernel_ms %.2f" % s.trace_ms)
+for i in range(1, 10):
+    print(f"  {names[i]:16s} {buf[i]:12d}   per wave-cast {buf[i] / max(1, buf[9]):8.2f}   per lane-cast {buf[i] / max(1, casts):7.3f}")
