@@ -54,7 +54,7 @@ struct pt_ctx {
 	bool prepared = false;
 
 	// device-resident scene
-	DevBuf geo, mat, cell_start, cell_items, obj_range, dirs, disc, samples, offsets, frame_dev, fb, accum, counter, stats_dev, scratch;
+	DevBuf geo, mat, cell_start, cell_items, cell_entries, obj_range, dirs, disc, samples, offsets, frame_dev, fb, accum, counter, stats_dev, scratch;
 	uint32_t* abort_flag = nullptr;      // host-pinned, read by the trace kernel
 	uint32_t* abort_flag_dev = nullptr;  // the same word as the device addresses it
 	uint32_t* counter_host = nullptr;    // host-pinned landing word for progress polls
@@ -186,6 +186,19 @@ int prepare(pt_ctx* c) {
 	std::vector<uint32_t> ranges;
 	bool coop = pt::object_ranges(rec.data(), n, gd, &ranges);
 	if((rc = upload(c, c->obj_range, ranges.data(), ranges.size() * 4))) return rc;
+	{
+		// the cooperative cast reads, per list entry, everything its collection step needs in one place
+		std::vector<float> entries(coop ? cell_items.size() * 8 : 8, 0.0f);
+		for(size_t k = 0; coop && k < cell_items.size(); k++) {
+			const uint32_t id = cell_items[k];
+			const float* r = rec.data() + (size_t)id * PT_F_STRIDE;
+			float* e = entries.data() + k * 8;
+			e[0] = r[PT_F_POS]; e[1] = r[PT_F_POS + 1]; e[2] = r[PT_F_POS + 2]; e[3] = r[PT_F_BRADIUS];
+			memcpy(e + 4, &id, 4);
+			memcpy(e + 5, &ranges[(size_t)id * 2], 8);
+		}
+		if((rc = upload(c, c->cell_entries, entries.data(), entries.size() * 4))) return rc;
+	}
 	if((rc = upload(c, c->dirs, dirs4.data(), dirs4.size() * 4))) return rc;
 	if((rc = upload(c, c->disc, disc.data(), disc.size() * sizeof(pt::f2)))) return rc;
 	if((rc = upload(c, c->samples, samples.data(), samples.size() * sizeof(pt::f2)))) return rc;
@@ -210,6 +223,7 @@ int prepare(pt_ctx* c) {
 	j.scene.cell_start = c->cell_start.as<uint32_t>();
 	j.scene.cell_items = c->cell_items.as<uint32_t>();
 	j.scene.obj_range = c->obj_range.as<uint32_t>();
+	j.scene.cell_entries = c->cell_entries.as<float4>();
 	j.scene.coop = coop ? 1 : 0;
 	j.scene.dirs = c->dirs.as<float4>();
 	j.scene.disc = c->disc.as<float2>();
@@ -402,7 +416,7 @@ void pt_destroy(pt_ctx* c) {
 	if(c->active.load()) { *c->abort_flag = 1; join_worker(c); }
 	(void)hipSetDevice(c->device);
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
-	for(DevBuf* b : { &c->geo, &c->mat, &c->cell_start, &c->cell_items, &c->obj_range, &c->dirs, &c->disc, &c->samples, &c->offsets, &c->frame_dev, &c->fb, &c->accum, &c->counter, &c->stats_dev, &c->scratch }) b->release();
+	for(DevBuf* b : { &c->geo, &c->mat, &c->cell_start, &c->cell_items, &c->cell_entries, &c->obj_range, &c->dirs, &c->disc, &c->samples, &c->offsets, &c->frame_dev, &c->fb, &c->accum, &c->counter, &c->stats_dev, &c->scratch }) b->release();
 	for(auto& p : c->pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
 	for(hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
 	if(c->abort_flag) (void)hipHostFree(c->abort_flag);

@@ -34,6 +34,7 @@ struct Scene {
 	cf4 geo, mat, dirs;
 	cf2 disc, samples;
 	cu32 cell_start, cell_items, obj_range;
+	cf4 entries;                 // per cell-list entry: {centre, bounding radius}, {entity, cell range lo, hi, 0}
 	ci32 offsets;
 	int n, brute;
 	Grid grid;
@@ -42,7 +43,7 @@ __device__ __forceinline__ Scene scene_view(const ptl::SceneDev& d) {
 	Scene s;
 	s.geo = (cf4)d.geo; s.mat = (cf4)d.mat; s.dirs = (cf4)d.dirs;
 	s.disc = (cf2)d.disc; s.samples = (cf2)d.samples;
-	s.cell_start = (cu32)d.cell_start; s.cell_items = (cu32)d.cell_items; s.obj_range = (cu32)d.obj_range;
+	s.cell_start = (cu32)d.cell_start; s.cell_items = (cu32)d.cell_items; s.obj_range = (cu32)d.obj_range; s.entries = (cf4)d.cell_entries;
 	s.offsets = (ci32)d.offsets;
 	s.n = d.n; s.brute = d.brute; s.grid = d.grid;
 	return s;
@@ -513,32 +514,30 @@ PT_DEV int cast(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface& surf
 }
 
 // ---- wave-cooperative grid cast ------------------------------------------------------------------
-// Same results as cast_grid, organised for wave64: the per-lane walk only COLLECTS candidates (cheap:
-// cell list reads, a duplicate check and a conservative bounding-sphere filter), the collected
-// (ray, entity) pairs of the whole wavefront are binned by intersection kind in LDS, and the
-// expensive analytic intersections then run one kind at a time with lanes taken from the bins, so a
-// wavefront executes one straight-line variant with (nearly) all lanes busy instead of the union of
-// all variants with a few.  Collection runs a segment of COOP_CELLS cells ahead of the decision
-// which cell wins; the reference's rule (first visited cell with a hit inside it; nearest hit in
-// that cell; lowest id on equal distance; code/raycast.cpp:957-983) is restored exactly by a 64-bit
-// key (cell ordinal | distance bits | id) reduced with an LDS atomic min per ray.
+// Same results as cast_grid, organised for wave64.  A segment of the cast has three phases:
+//   walk     every walking lane steps COOP_CELLS cells ahead and only notes, per non-empty cell, where
+//            its list starts and how long it is (one descriptor in LDS);
+//   expand   the lists of all lanes are flattened into one sequence of (ray, cell, entry) items that
+//            the 64 lanes share evenly, whatever the ray they belong to: each item is one 32-byte
+//            read, a duplicate check against the ray's previous cell and a conservative
+//            bounding-sphere filter; survivors go into a pool, tagged with their intersection kind;
+//   test     the pool is grouped by kind and the expensive analytic intersections run one kind at a
+//            time with lanes taken from the bins, so a wavefront executes one straight-line variant
+//            with many lanes busy instead of the union of all variants with a few.
+// Collection runs ahead of the decision which cell wins; the reference's rule (first visited cell
+// with a hit inside it; nearest hit in that cell; lowest id on equal distance;
+// code/raycast.cpp:957-983) is restored exactly by a 64-bit key (cell ordinal | distance bits | id)
+// reduced with an LDS atomic min per ray.
 #ifndef PT_COOP_CELLS
 #define PT_COOP_CELLS 8
-#endif
-#ifndef PT_COOP_BUDGET
-#define PT_COOP_BUDGET 8
-#endif
-constexpr int COOP_CELLS = PT_COOP_CELLS;     // cells a lane records per segment
-constexpr int COOP_BUDGET = PT_COOP_BUDGET;   // candidates a lane may submit per segment
-constexpr int COOP_POOL = 64 * COOP_BUDGET;
-#ifndef PT_COOP_LOOK
-#define PT_COOP_LOOK 1
 #endif
 #ifndef PT_COOP_MIN_WALKING
 #define PT_COOP_MIN_WALKING 56
 #endif
+constexpr int COOP_CELLS = PT_COOP_CELLS;               // cells a lane records per segment
+constexpr int COOP_POOL = 256;                          // candidates awaiting their intersection test
+constexpr int COOP_DESCS = 192;                         // non-empty cells the wavefront can note per segment
 constexpr int COOP_MIN_WALKING = PT_COOP_MIN_WALKING;   // fewer walking lanes than this: return and refill
-constexpr int COOP_LOOK = PT_COOP_LOOK;        // cells whose list bounds are fetched ahead in one go
 constexpr uint64_t COOP_NONE = ~0ull;
 
 struct CoopShared {                           // one per wavefront
@@ -547,23 +546,46 @@ struct CoopShared {                           // one per wavefront
 	uint32_t ncell[64];
 	unsigned long long best[64];              // winning key per ray
 	float res[6][64];                         // hit position, normal of the winner
-	uint32_t pool[COOP_POOL];                 // submitted candidates: owner lane << 26 | kind << 23 | entity
+	uint32_t pool[COOP_POOL];                 // candidates: owner lane << 26 | kind << 23 | entity
 	uint32_t sorted[COOP_POOL];               // the same, grouped by kind
 	uint32_t count[KIND_COUNT + 2];           // per kind, [KIND_COUNT] = total
 	uint32_t fill[KIND_COUNT + 2];
+	unsigned long long work;                  // descriptors noted << 32 | list entries they cover
+	uint32_t desc_k0[COOP_DESCS];             // first entry of the cell's list
+	uint32_t desc_start[COOP_DESCS + 1];      // position of that entry in the flattened sequence
+	uint16_t desc_who[COOP_DESCS];            // owner lane | cell ordinal << 6
+#ifdef PT_COOP_TIMING
+	unsigned long long tacc[16];              // per-phase cycle sums of this wavefront
+#endif
 };
+#ifndef PT_COOP_TIMING
+static_assert(sizeof(CoopShared) <= 10240, "four wavefronts per SIMD need the per-wave LDS share within 10 KB");
+#endif
 
-#ifdef PT_COOP_STATS
-#define PT_STAT(i, v) atomicAdd((unsigned long long*)&g_coop_stats[i], (unsigned long long)(v))
+// Diagnostic builds: -DPT_COOP_STATS counts events of the cooperative cast, -DPT_COOP_TIMING adds up
+// the cycles each wavefront spends per phase (build one or the other: the event atomics distort timing).
+#if defined(PT_COOP_STATS) || defined(PT_COOP_TIMING)
 __device__ unsigned long long g_coop_stats[16];
+#define PT_COUNT_(i, v) atomicAdd((unsigned long long*)&g_coop_stats[i], (unsigned long long)(v))
+#endif
+#ifdef PT_COOP_STATS
+#define PT_STAT(i, v) PT_COUNT_(i, v)
 #else
 #define PT_STAT(i, v)
+#endif
+#ifdef PT_COOP_TIMING
+#define PT_TICK(var) long long var = clock64()
+#define PT_TOCK(sh_, i, var) { long long now_ = clock64(); if(lane == 0) (sh_).tacc[i] += (unsigned long long)(now_ - var); var = now_; }
+#else
+#define PT_TICK(var)
+#define PT_TOCK(sh_, i, var)
 #endif
 PT_DEV void wave_sync() {
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+PT_DEV uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 PT_DEV uint32_t pack_cell(int x, int y, int z) { return (uint32_t)x | ((uint32_t)y << 10) | ((uint32_t)z << 20); }
 PT_DEV bool range_has(uint32_t lo, uint32_t hi, uint32_t c) {
 	uint32_t cx = c & 1023, cy = (c >> 10) & 1023, cz = (c >> 20) & 1023;
@@ -627,15 +649,37 @@ PT_DEV void coop_chunk(const Scene& sc, CoopShared& sh, uint32_t base, uint32_t 
 	}
 }
 
-// What a lane keeps of a cast between calls: the walker, the resume point inside a partly submitted
-// cell and the best hit found in that cell so far (its position and normal stay in CoopShared::res).
+// Tests everything in the pool and empties it.  Whole wavefront.
+PT_DEV void coop_drain(const Scene& sc, CoopShared& sh, int lane) {
+	uint32_t off[KIND_COUNT + 1];
+	off[0] = 0;
+	#pragma unroll
+	for(int k = 0; k < KIND_COUNT; k++) off[k + 1] = off[k] + uniform(sh.count[k]);
+	const uint32_t total = off[KIND_COUNT];
+	if(total == 0) return;
+	for(uint32_t i = (uint32_t)lane; i < total; i += 64) {
+		uint32_t e = sh.pool[i];
+		uint32_t kind = (e >> 23) & 7u;
+		uint32_t base = kind == 0 ? off[0] : kind == 1 ? off[1] : kind == 2 ? off[2] : kind == 3 ? off[3] : kind == 4 ? off[4] : off[5];
+		sh.sorted[base + atomicAdd(&sh.fill[kind], 1u)] = e;
+	}
+	wave_sync();
+	for(uint32_t base = off[0]; base < off[1]; base += 64) coop_chunk<KIND_SPHERE>(sc, sh, base, off[1], lane);
+	for(uint32_t base = off[1]; base < off[2]; base += 64) coop_chunk<KIND_BOX>(sc, sh, base, off[2], lane);
+	for(uint32_t base = off[2]; base < off[3]; base += 64) coop_chunk<KIND_BOX_ROTATED>(sc, sh, base, off[3], lane);
+	for(uint32_t base = off[3]; base < off[4]; base += 64) coop_chunk<KIND_ELLIPSOID>(sc, sh, base, off[4], lane);
+	for(uint32_t base = off[4]; base < off[5]; base += 64) coop_chunk<KIND_CYLINDER>(sc, sh, base, off[5], lane);
+	for(uint32_t base = off[5]; base < off[6]; base += 64) coop_chunk<KIND_CONE>(sc, sh, base, off[6], lane);
+	if(lane < KIND_COUNT + 2) { sh.count[lane] = 0; sh.fill[lane] = 0; }
+	wave_sync();
+}
+
+// What a lane keeps of a cast between calls.
 struct CoopLane {
 	WalkLite w;
-	int k_resume;
-	unsigned long long carry;
 	bool walking;
 };
-PT_DEV void coop_lane_reset(CoopLane& st) { st.k_resume = -1; st.carry = COOP_NONE; st.walking = false; }
+PT_DEV void coop_lane_reset(CoopLane& st) { st.walking = false; }
 
 // All 64 lanes must call this together; `active` lanes own a ray, the others only lend a hand.
 // A lane with `fresh` set starts the cast of (rp, rd); an active lane without it continues the cast
@@ -661,115 +705,127 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 
 	if(lane == 0 && __ballot(walking) != 0) PT_STAT(9, 1);
 	while(__ballot(walking) != 0) {
+#ifdef PT_COOP_TIMING
+		if(lane == 0) sh.tacc[1] += 1;
+#endif
 		if(lane == 0) PT_STAT(1, 1);
+		PT_TICK(t0);
 		// ---- reset the wavefront's bins --------------------------------------------------------
 		if(lane < KIND_COUNT + 2) { sh.count[lane] = 0; sh.fill[lane] = 0; }
-		sh.best[lane] = walking ? st.carry : COOP_NONE;    // a carried hit keeps its position and normal in sh.res
+		if(lane == 0) sh.work = 0;
+		sh.best[lane] = COOP_NONE;
 		sh.ncell[lane] = 0;
 		wave_sync();
 
-		// ---- phase 1: every walking lane collects candidates along its ray -----------------------
-		// The cell-list bounds of the next COOP_LOOK cells are fetched together (a probe copy of the
-		// walker runs ahead), so a run of empty cells costs one memory round trip, not one per cell.
-		int recorded = 0;
-		bool partial = false;
+		// ---- walk: note the non-empty cells of the next COOP_CELLS steps ---------------------------
+		// A probe copy of the walker runs through the whole segment first, so the list bounds of
+		// all its cells are fetched in one memory round trip.
+		int recorded = 0, m = 0;
+		bool more = true;
+		WalkLite probe = st.w;
 		if(walking) {
-			int submitted = 0;
-			uint32_t prev = 0xffffffffu;
-			bool stop = false;
-			while(!stop) {
-				int pc[COOP_LOOK];
-				uint32_t ka[COOP_LOOK], kb[COOP_LOOK];
-				int m = 0;
-				{
-					WalkLite probe = st.w;
-					bool more = true;
-					#pragma unroll
-					for(int j = 0; j < COOP_LOOK; j++) {
-						pc[j] = 0;
-						if(more) { pc[j] = lite_cell(sc.grid, probe); m = j + 1; if(j + 1 < COOP_LOOK) more = lite_next(sc.grid, probe); }
-					}
-					#pragma unroll
-					for(int j = 0; j < COOP_LOOK; j++) { ka[j] = sc.cell_start[pc[j]]; kb[j] = sc.cell_start[pc[j] + 1]; }
-				}
-				#pragma unroll
-				for(int j = 0; j < COOP_LOOK; j++) {
-					if(j < m && !stop) {
-						uint32_t k0 = ka[j], k1 = kb[j];
-						const bool resumed = st.k_resume >= 0;
-						if(resumed) k0 = (uint32_t)st.k_resume;
-						uint32_t here = pack_cell(st.w.cx, st.w.cy, st.w.cz);
-						sh.cells[recorded][lane] = here;
-						recorded++;
-						for(uint32_t k = k0; k < k1; k++) {
-							int id = (int)sc.cell_items[k];
-							PT_STAT(5, 1);
-							uint32_t lo = sc.obj_range[2 * id], hi = sc.obj_range[2 * id + 1];
-							if(prev != 0xffffffffu && range_has(lo, hi, prev)) { PT_STAT(6, 1); continue; }     // submitted one cell earlier
-							v4f p0 = sc.geo[(size_t)G_POS * sc.n + id];
-							if(sphere_rejects(rp, rd, p0)) { PT_STAT(7, 1); continue; }
-							if(submitted == COOP_BUDGET) { partial = true; st.k_resume = (int)k; break; }
-							uint32_t kind = (lo >> 30) | ((hi >> 30) << 2);
-							uint32_t slot = atomicAdd(&sh.count[KIND_COUNT], 1u);
-							atomicAdd(&sh.count[kind], 1u);
-							sh.pool[slot] = ((uint32_t)lane << 26) | (kind << 23) | (uint32_t)id;
-							submitted++;
-						}
-						if(partial) { stop = true; }
-						else {
-							st.k_resume = -1;
-							// entities of a cell that was only partly submitted in THIS segment (its head went
-							// into the previous one) must not be treated as already submitted by the next cell
-							prev = resumed ? 0xffffffffu : here;
-							if(!lite_next(sc.grid, st.w)) { walking = false; stop = true; }
-							else if(recorded == COOP_CELLS) stop = true;
+			int pc[COOP_CELLS];
+			uint32_t cc[COOP_CELLS], ka[COOP_CELLS], kb[COOP_CELLS];
+			#pragma unroll
+			for(int j = 0; j < COOP_CELLS; j++) {
+				pc[j] = 0; cc[j] = 0;
+				if(more) { pc[j] = lite_cell(sc.grid, probe); cc[j] = pack_cell(probe.cx, probe.cy, probe.cz); m = j + 1; more = lite_next(sc.grid, probe); }
+			}
+			#pragma unroll
+			for(int j = 0; j < COOP_CELLS; j++) { ka[j] = sc.cell_start[pc[j]]; kb[j] = sc.cell_start[pc[j] + 1]; }
+			bool open = true;
+			#pragma unroll
+			for(int j = 0; j < COOP_CELLS; j++) {
+				if(j < m && open) {
+					uint32_t c = kb[j] - ka[j];
+					if(c > 0) {
+						unsigned long long old = atomicAdd(&sh.work, (1ull << 32) | (unsigned long long)c);
+						uint32_t slot = (uint32_t)(old >> 32), start = (uint32_t)old;
+						if(slot >= (uint32_t)COOP_DESCS) {
+							// no descriptor left this segment: this cell and the ones after it wait for the next
+							if(slot == (uint32_t)COOP_DESCS) sh.desc_start[COOP_DESCS] = start;
+							open = false;
+						} else {
+							sh.desc_k0[slot] = ka[j];
+							sh.desc_start[slot] = start;
+							sh.desc_who[slot] = (uint16_t)((uint32_t)lane | ((uint32_t)j << 6));
 						}
 					}
+					if(open) { sh.cells[j][lane] = cc[j]; recorded = j + 1; }
 				}
 			}
 			sh.ncell[lane] = (uint32_t)recorded;
 			PT_STAT(4, recorded);
 		}
 		wave_sync();
+		PT_TOCK(sh, 10, t0);
 
-		// ---- phase 2: group the submissions by kind, then intersect one kind at a time -----------
-		uint32_t off[KIND_COUNT + 1];
-		off[0] = 0;
-		#pragma unroll
-		for(int k = 0; k < KIND_COUNT; k++) off[k + 1] = off[k] + sh.count[k];
-		uint32_t total = off[KIND_COUNT];
-		for(uint32_t i = (uint32_t)lane; i < total; i += 64) {
-			uint32_t e = sh.pool[i];
-			uint32_t kind = (e >> 23) & 7u;
-			uint32_t base = kind == 0 ? off[0] : kind == 1 ? off[1] : kind == 2 ? off[2] : kind == 3 ? off[3] : kind == 4 ? off[4] : off[5];
-			sh.sorted[base + atomicAdd(&sh.fill[kind], 1u)] = e;
-		}
-		wave_sync();
-		for(uint32_t base = off[0]; base < off[1]; base += 64) coop_chunk<KIND_SPHERE>(sc, sh, base, off[1], lane);
-		for(uint32_t base = off[1]; base < off[2]; base += 64) coop_chunk<KIND_BOX>(sc, sh, base, off[2], lane);
-		for(uint32_t base = off[2]; base < off[3]; base += 64) coop_chunk<KIND_BOX_ROTATED>(sc, sh, base, off[3], lane);
-		for(uint32_t base = off[3]; base < off[4]; base += 64) coop_chunk<KIND_ELLIPSOID>(sc, sh, base, off[4], lane);
-		for(uint32_t base = off[4]; base < off[5]; base += 64) coop_chunk<KIND_CYLINDER>(sc, sh, base, off[5], lane);
-		for(uint32_t base = off[5]; base < off[6]; base += 64) coop_chunk<KIND_CONE>(sc, sh, base, off[6], lane);
-		wave_sync();
-
-		// ---- phase 3: each owner reads its verdict -----------------------------------------------
-		if(recorded > 0) {
-			unsigned long long key = sh.best[lane];
-			if(key != COOP_NONE) {
-				int ord = (int)(key >> 55);
-				if(partial && ord == recorded - 1) {
-					// the best hit lies in the cell whose list is not exhausted yet: keep it, go on with that cell
-					st.carry = key & ((1ull << 55) - 1);
-				} else {
-					result = (int)(key & 0x7fffffu) + 1;
-					hpos = v3(sh.res[0][lane], sh.res[1][lane], sh.res[2][lane]);
-					hnrm = v3(sh.res[3][lane], sh.res[4][lane], sh.res[5][lane]);
-					walking = false;
-					st.carry = COOP_NONE;
+		// ---- expand: the lists of all lanes as one sequence, 64 entries per round ------------------
+		const unsigned long long work = sh.work;
+		const uint32_t noted = uniform((uint32_t)(work >> 32));
+		const uint32_t ndesc = noted < (uint32_t)COOP_DESCS ? noted : (uint32_t)COOP_DESCS;
+		const uint32_t total = uniform(noted > (uint32_t)COOP_DESCS ? sh.desc_start[COOP_DESCS] : (uint32_t)work);
+		for(uint32_t base = 0; base < total; base += 64) {
+			const uint32_t i = base + (uint32_t)lane;
+			if(i < total) {
+				uint32_t d = 0;
+				#pragma unroll
+				for(uint32_t step = 128; step >= 1; step >>= 1) {     // last descriptor that starts at or before i
+					uint32_t t = d + step;
+					if(t < ndesc && sh.desc_start[t] <= i) d = t;
+				}
+				const uint32_t k = sh.desc_k0[d] + (i - sh.desc_start[d]);
+				const uint32_t who = sh.desc_who[d];
+				const int owner = (int)(who & 63u), ord = (int)(who >> 6);
+				const v4f e0 = sc.entries[2 * (size_t)k];
+				const v4f e1 = sc.entries[2 * (size_t)k + 1];
+				const uint32_t id = __float_as_uint(e1.x), lo = __float_as_uint(e1.y), hi = __float_as_uint(e1.z);
+				PT_STAT(5, 1);
+				// an entity that also lies in the ray's previous cell was collected there (the cells of a
+				// ray inside an entity's box-shaped range are consecutive)
+				bool dup = false;
+				if(ord > 0) dup = range_has(lo, hi, sh.cells[ord - 1][owner]);
+				if(dup) PT_STAT(6, 1);
+				if(!dup) {
+					V3 op = v3(sh.ray[0][owner], sh.ray[1][owner], sh.ray[2][owner]);
+					V3 od = v3(sh.ray[3][owner], sh.ray[4][owner], sh.ray[5][owner]);
+					if(!sphere_rejects(op, od, e0)) {
+						uint32_t kind = (lo >> 30) | ((hi >> 30) << 2);
+						uint32_t slot = atomicAdd(&sh.count[KIND_COUNT], 1u);
+						atomicAdd(&sh.count[kind], 1u);
+						sh.pool[slot] = ((uint32_t)owner << 26) | (kind << 23) | id;
+					} else PT_STAT(7, 1);
 				}
 			}
+			wave_sync();
+			if(uniform(sh.count[KIND_COUNT]) > (uint32_t)(COOP_POOL - 64)) {
+				PT_TOCK(sh, 11, t0);
+				coop_drain(sc, sh, lane);
+				PT_TOCK(sh, 12, t0);
+			}
 		}
+		PT_TOCK(sh, 11, t0);
+
+		// ---- test what is left in the pool ------------------------------------------------------------
+		coop_drain(sc, sh, lane);
+		PT_TOCK(sh, 12, t0);
+
+		// ---- verdict: every list of every recorded cell has been tested ------------------------------
+		if(walking) {
+			unsigned long long key = recorded > 0 ? sh.best[lane] : COOP_NONE;
+			if(key != COOP_NONE) {
+				result = (int)(key & 0x7fffffu) + 1;
+				hpos = v3(sh.res[0][lane], sh.res[1][lane], sh.res[2][lane]);
+				hnrm = v3(sh.res[3][lane], sh.res[4][lane], sh.res[5][lane]);
+				walking = false;
+			} else if(recorded == m) {
+				if(more) st.w = probe;       // the probe stands on the first cell of the next segment
+				else walking = false;        // the ray has left the grid
+			} else {
+				for(int j = 0; j < recorded; j++) lite_next(sc.grid, st.w);   // stopped early: resume at the first cell not recorded
+			}
+		}
+		PT_TOCK(sh, 13, t0);
 		if(__popcll(__ballot(walking)) < COOP_MIN_WALKING) break;
 	}
 	st.walking = walking;

@@ -63,6 +63,11 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 	CoopLane walk_state;
 	coop_lane_reset(walk_state);
 	bool fresh = true;
+#ifdef PT_COOP_TIMING
+	if(lane < 16) coop.tacc[lane] = 0;
+#endif
+	PT_TICK(t_kernel);
+	PT_TICK(t_loop);
 
 	for(;;) {
 		// ---- stage 0: lanes without a pixel draw one from the wave's pool -------------------
@@ -134,10 +139,12 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 		surf.m0 = (v4f)(0.0f); surf.m1 = (v4f){ 0.0f, 0.0f, 0.0f, 1.0f }; surf.rough = 0;
 		int id = 0;
 		bool landed = flying;
+		PT_TOCK(coop, 15, t_loop);
 		if(MODE == CAST_GRID_COOP) {
 			// the whole wavefront takes part; lanes whose walk is not over yet stay in flight and resume
 			id = cast_grid_coop(sc, coop, lane, flying, fresh, walk_state, rp, rd, hp, hn, surf, landed);
 			fresh = landed || !flying;
+			PT_TOCK(coop, 14, t_loop);
 		} else if(flying) {
 			uint64_t unused = 0;
 			id = MODE == CAST_BRUTE ? cast_all(sc, rp, rd, hp, hn, surf) : cast_grid<false>(sc, rp, rd, hp, hn, surf, unused);
@@ -169,6 +176,11 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 		}
 	}
 
+	PT_TOCK(coop, 15, t_loop);
+	PT_TOCK(coop, 0, t_kernel);
+#ifdef PT_COOP_TIMING
+	if(lane == 0) for(int i = 0; i < 16; i++) PT_COUNT_(i, coop.tacc[i]);
+#endif
 	// ray-cast count: one atomic per wave
 	if(job.stats) {
 		uint32_t total = casts;
@@ -252,7 +264,7 @@ const char* trace_kernel_name() { return "pt_k_trace"; }
 
 // Diagnostic build only (-DPT_COOP_STATS): copies and clears the cooperative cast's event counters.
 int coop_stats(unsigned long long* out16) {
-#ifdef PT_COOP_STATS
+#if defined(PT_COOP_STATS) || defined(PT_COOP_TIMING)
 	unsigned long long zero[16] = { 0 };
 	if(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_coop_stats), sizeof zero) != hipSuccess) return -1;
 	if(hipMemcpyToSymbol(HIP_SYMBOL(g_coop_stats), zero, sizeof zero) != hipSuccess) return -1;

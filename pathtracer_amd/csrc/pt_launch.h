@@ -16,6 +16,7 @@ struct SceneDev {
 	const float4* mat;
 	const uint32_t* cell_start;
 	const uint32_t* cell_items;
+	const float4* cell_entries; // cooperative cast: two float4 per cell_items entry (bounding sphere; entity, cell range)
 	const uint32_t* obj_range;  // per entity: inclusive cell range, 10 bits per axis, and its intersection kind (2 words)
 	const float4* dirs;
 	const float2* disc;

@@ -21,5 +21,9 @@ s = r.stats()
 names = ["", "segments", "chunks", "tests", "cells", "items", "deduped", "sphere_rejected", "accepted", "wave_casts"]
 casts = s.rays
 print(name, "casts", casts, "kernel_ms %.2f" % s.trace_ms)
+names += ["cyc_collect", "cyc_sort", "cyc_chunks", "cyc_verdict", "cyc_cast", "cyc_generate_shade"]
+print("  wave cycles total %d" % buf[0])
+for i in range(10, 16):
+    print(f"  {names[i]:20s} {buf[i]:14d}  {100.0 * buf[i] / max(1, buf[0]):5.1f} % of wave time   per segment {buf[i] / max(1, buf[1]):8.0f}")
 for i in range(1, 10):
     print(f"  {names[i]:16s} {buf[i]:12d}   per wave-cast {buf[i] / max(1, buf[9]):8.2f}   per lane-cast {buf[i] / max(1, casts):7.3f}")
