@@ -54,7 +54,7 @@ struct pt_ctx {
 	bool prepared = false;
 
 	// device-resident scene
-	DevBuf geo, mat, cell_start, cell_items, cell_entries, obj_range, dirs, disc, samples, offsets, frame_dev, fb, accum, counter, stats_dev, scratch;
+	DevBuf geo, cell_start, cell_items, cell_entries, obj_range, dirs, disc, samples, offsets, frame_dev, fb, accum, counter, stats_dev, scratch;
 	uint32_t* abort_flag = nullptr;      // host-pinned, read by the trace kernel
 	uint32_t* abort_flag_dev = nullptr;  // the same word as the device addresses it
 	uint32_t* counter_host = nullptr;    // host-pinned landing word for progress polls
@@ -154,9 +154,9 @@ int prepare(pt_ctx* c) {
 		cell_items.clear();
 	}
 
-	// structure-of-arrays planes of float4 (layout documented in pt_device.h)
+	// one 128-byte record of eight float4 per entity (layout documented in pt_device.h)
 	const size_t np = (size_t)(n > 0 ? n : 1);
-	std::vector<float> geo(np * 6 * 4, 0.0f), mat(np * 2 * 4, 0.0f);
+	std::vector<float> geo(np * 8 * 4, 0.0f);
 	for(int i = 0; i < n; i++) {
 		const float* r = rec.data() + (size_t)i * PT_F_STRIDE;
 		int32_t type, flags;
@@ -165,22 +165,21 @@ int prepare(pt_ctx* c) {
 		int32_t tf = type | (flags << 8);
 		float tf_bits;
 		memcpy(&tf_bits, &tf, 4);
-		auto plane = [&](std::vector<float>& v, int p) { return v.data() + ((size_t)p * np + (size_t)i) * 4; };
-		float* g0 = plane(geo, 0); g0[0] = r[PT_F_POS]; g0[1] = r[PT_F_POS + 1]; g0[2] = r[PT_F_POS + 2]; g0[3] = r[PT_F_BRADIUS];
-		memcpy(plane(geo, 1), r + PT_F_ROT, 16);
-		memcpy(plane(geo, 2), r + PT_F_ROTINV, 16);
-		float* g3 = plane(geo, 3); g3[0] = r[PT_F_DIM]; g3[1] = r[PT_F_DIM + 1]; g3[2] = r[PT_F_DIM + 2]; g3[3] = tf_bits;
-		float* g4 = plane(geo, 4); g4[0] = r[PT_F_SCALE]; g4[1] = r[PT_F_SCALE + 1]; g4[2] = r[PT_F_SCALE + 2]; g4[3] = r[PT_F_ROUGH];
-		float* g5 = plane(geo, 5); g5[0] = r[PT_F_SCALEINV]; g5[1] = r[PT_F_SCALEINV + 1]; g5[2] = r[PT_F_SCALEINV + 2]; g5[3] = 0;
-		float* m0 = plane(mat, 0); m0[0] = r[PT_F_COLOR]; m0[1] = r[PT_F_COLOR + 1]; m0[2] = r[PT_F_COLOR + 2]; m0[3] = r[PT_F_REFL];
-		float* m1 = plane(mat, 1); m1[0] = r[PT_F_EMIT]; m1[1] = r[PT_F_EMIT + 1]; m1[2] = r[PT_F_EMIT + 2]; m1[3] = r[PT_F_IOR];
+		auto slot = [&](int p) { return geo.data() + ((size_t)i * 8 + (size_t)p) * 4; };
+		float* g0 = slot(0); g0[0] = r[PT_F_POS]; g0[1] = r[PT_F_POS + 1]; g0[2] = r[PT_F_POS + 2]; g0[3] = r[PT_F_BRADIUS];
+		memcpy(slot(1), r + PT_F_ROT, 16);
+		memcpy(slot(2), r + PT_F_ROTINV, 16);
+		float* g3 = slot(3); g3[0] = r[PT_F_DIM]; g3[1] = r[PT_F_DIM + 1]; g3[2] = r[PT_F_DIM + 2]; g3[3] = tf_bits;
+		float* g4 = slot(4); g4[0] = r[PT_F_SCALE]; g4[1] = r[PT_F_SCALE + 1]; g4[2] = r[PT_F_SCALE + 2]; g4[3] = r[PT_F_ROUGH];
+		float* g5 = slot(5); g5[0] = r[PT_F_SCALEINV]; g5[1] = r[PT_F_SCALEINV + 1]; g5[2] = r[PT_F_SCALEINV + 2]; g5[3] = 0;
+		float* m0 = slot(6); m0[0] = r[PT_F_COLOR]; m0[1] = r[PT_F_COLOR + 1]; m0[2] = r[PT_F_COLOR + 2]; m0[3] = r[PT_F_REFL];
+		float* m1 = slot(7); m1[0] = r[PT_F_EMIT]; m1[1] = r[PT_F_EMIT + 1]; m1[2] = r[PT_F_EMIT + 2]; m1[3] = r[PT_F_IOR];
 	}
 	std::vector<float> dirs4((size_t)PT_TABLE_COUNT * 4, 0.0f);
 	for(int i = 0; i < PT_TABLE_COUNT; i++) { dirs4[(size_t)i * 4] = dirs[(size_t)i].x; dirs4[(size_t)i * 4 + 1] = dirs[(size_t)i].y; dirs4[(size_t)i * 4 + 2] = dirs[(size_t)i].z; }
 
 	int rc;
 	if((rc = upload(c, c->geo, geo.data(), geo.size() * 4))) return rc;
-	if((rc = upload(c, c->mat, mat.data(), mat.size() * 4))) return rc;
 	if((rc = upload(c, c->cell_start, cell_start.data(), cell_start.size() * 4))) return rc;
 	if((rc = upload(c, c->cell_items, cell_items.data(), cell_items.size() * 4))) return rc;
 	std::vector<uint32_t> ranges;
@@ -219,7 +218,6 @@ int prepare(pt_ctx* c) {
 	ptl::TraceJob& j = c->job;
 	j = ptl::TraceJob{};
 	j.scene.geo = c->geo.as<float4>();
-	j.scene.mat = c->mat.as<float4>();
 	j.scene.cell_start = c->cell_start.as<uint32_t>();
 	j.scene.cell_items = c->cell_items.as<uint32_t>();
 	j.scene.obj_range = c->obj_range.as<uint32_t>();
@@ -416,7 +414,7 @@ void pt_destroy(pt_ctx* c) {
 	if(c->active.load()) { *c->abort_flag = 1; join_worker(c); }
 	(void)hipSetDevice(c->device);
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
-	for(DevBuf* b : { &c->geo, &c->mat, &c->cell_start, &c->cell_items, &c->cell_entries, &c->obj_range, &c->dirs, &c->disc, &c->samples, &c->offsets, &c->frame_dev, &c->fb, &c->accum, &c->counter, &c->stats_dev, &c->scratch }) b->release();
+	for(DevBuf* b : { &c->geo, &c->cell_start, &c->cell_items, &c->cell_entries, &c->obj_range, &c->dirs, &c->disc, &c->samples, &c->offsets, &c->frame_dev, &c->fb, &c->accum, &c->counter, &c->stats_dev, &c->scratch }) b->release();
 	for(auto& p : c->pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
 	for(hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
 	if(c->abort_flag) (void)hipHostFree(c->abort_flag);

@@ -31,7 +31,7 @@ using Grid = ptl::GridDev;
 typedef const PT_CONST ptl::FrameDev* FrameRef;
 
 struct Scene {
-	cf4 geo, mat, dirs;
+	cf4 geo, dirs;
 	cf2 disc, samples;
 	cu32 cell_start, cell_items, obj_range;
 	cf4 entries;                 // per cell-list entry: {centre, bounding radius}, {entity, cell range lo, hi, 0}
@@ -41,7 +41,7 @@ struct Scene {
 };
 __device__ __forceinline__ Scene scene_view(const ptl::SceneDev& d) {
 	Scene s;
-	s.geo = (cf4)d.geo; s.mat = (cf4)d.mat; s.dirs = (cf4)d.dirs;
+	s.geo = (cf4)d.geo; s.dirs = (cf4)d.dirs;
 	s.disc = (cf2)d.disc; s.samples = (cf2)d.samples;
 	s.cell_start = (cu32)d.cell_start; s.cell_items = (cu32)d.cell_items; s.obj_range = (cu32)d.obj_range; s.entries = (cf4)d.cell_entries;
 	s.offsets = (ci32)d.offsets;
@@ -111,12 +111,13 @@ PT_DEV uint32_t rng_bounded(Rng& r) {
 }
 
 // ---- scene as the kernels see it ----------------------------------------------------------------
-// Entities are flattened into structure-of-arrays planes of v4f, split by use: six geometry
-// planes read while intersecting and two material planes read once per hit.
+// An entity is one 128-byte record of eight v4f (one cache line, so a lane that tests an entity
+// touches one line, and a wave-uniform index turns into wide scalar loads): six geometry slots read
+// while intersecting and two material slots read once per hit.
 //   G0 pos.xyz | bounding-sphere radius     G1 rot (w,x,y,z)          G2 rotInverse (w,x,y,z)
 //   G3 dim.xyz | type + flags<<8 (int bits) G4 dimScale.xyz | roughness   G5 dimScaleInverse.xyz | -
 //   M0 colorLinear.rgb | reflectionMod      M1 emitColorLinear.rgb | refractiveIndex
-enum { G_POS = 0, G_ROT = 1, G_ROTINV = 2, G_DIM = 3, G_SCALE = 4, G_SCALEINV = 5, G_PLANES = 6, M_COLOR = 0, M_EMIT = 1, M_PLANES = 2 };
+enum { G_POS = 0, G_ROT = 1, G_ROTINV = 2, G_DIM = 3, G_SCALE = 4, G_SCALEINV = 5, M_COLOR = 6, M_EMIT = 7, G_SLOTS = 8 };
 enum { FLAG_ROTATED = 1, FLAG_EVEN = 2 };
 
 // Material of the entity a ray hit: colorLinear|reflectionMod, emitColorLinear|refractiveIndex, roughness.
@@ -250,10 +251,10 @@ PT_DEV float hit_cone(V3 p, V3 d, V3& pos, V3& nrm) {
 	return distance;
 }
 
-// Entity record loader: planes are addressed [plane*n + index].
+// Entity record loader: one entity = G_SLOTS consecutive float4 (128 bytes, one cache line).
 struct GeoRef {
 	cf4 base; int n; int i;
-	PT_DEV v4f plane(int p) const { return base[(size_t)p * (size_t)n + (size_t)i]; }
+	PT_DEV v4f plane(int p) const { return base[(size_t)i * G_SLOTS + (size_t)p]; }
 };
 
 // transformToUnitSpace / transformToGlobalSpace (code/raycast.cpp:750-770)
@@ -440,9 +441,9 @@ PT_DEV uint64_t hash_cell(uint64_t h, int index) { return (h ^ (uint64_t)(uint32
 
 PT_DEV Surface surface_of(const Scene& sc, int index) {
 	Surface m;
-	m.m0 = sc.mat[(size_t)M_COLOR * sc.n + index];
-	m.m1 = sc.mat[(size_t)M_EMIT * sc.n + index];
-	m.rough = sc.geo[(size_t)G_SCALE * sc.n + index].w;
+	m.m0 = sc.geo[(size_t)index * G_SLOTS + M_COLOR];
+	m.m1 = sc.geo[(size_t)index * G_SLOTS + M_EMIT];
+	m.rough = sc.geo[(size_t)index * G_SLOTS + G_SCALE].w;
 	return m;
 }
 
@@ -535,8 +536,14 @@ PT_DEV int cast(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface& surf
 #define PT_COOP_MIN_WALKING 56
 #endif
 constexpr int COOP_CELLS = PT_COOP_CELLS;               // cells a lane records per segment
-constexpr int COOP_POOL = 256;                          // candidates awaiting their intersection test
-constexpr int COOP_DESCS = 192;                         // non-empty cells the wavefront can note per segment
+#ifndef PT_COOP_POOL
+#define PT_COOP_POOL 256
+#endif
+#ifndef PT_COOP_DESCS
+#define PT_COOP_DESCS 192
+#endif
+constexpr int COOP_POOL = PT_COOP_POOL;                 // candidates awaiting their intersection test
+constexpr int COOP_DESCS = PT_COOP_DESCS;               // non-empty cells the wavefront can note per segment (at most 511)
 constexpr int COOP_MIN_WALKING = PT_COOP_MIN_WALKING;   // fewer walking lanes than this: return and refill
 constexpr uint64_t COOP_NONE = ~0ull;
 
@@ -558,7 +565,7 @@ struct CoopShared {                           // one per wavefront
 	unsigned long long tacc[16];              // per-phase cycle sums of this wavefront
 #endif
 };
-#ifndef PT_COOP_TIMING
+#if !defined(PT_COOP_TIMING) && !defined(PT_TRACE_WAVES_PER_SIMD)
 static_assert(sizeof(CoopShared) <= 10240, "four wavefronts per SIMD need the per-wave LDS share within 10 KB");
 #endif
 
@@ -616,37 +623,69 @@ PT_DEV void coop_chunk(const Scene& sc, CoopShared& sh, uint32_t base, uint32_t 
 	if(lane == 0) PT_STAT(2, 1);
 	if(i < end) PT_STAT(3, 1);
 	V3 pos = v3(0, 0, 0), nrm = v3(0, 0, 0);
+	PT_TICK(tc);
+	float distance = -1;
+	int id = 0;
+	V3 rp = v3(0, 0, 0), rd = v3(0, 0, 1);
 	if(i < end) {
 		uint32_t entry = sh.sorted[i];
 		owner = (int)(entry >> 26);
-		int id = (int)(entry & 0x7fffffu);
-		V3 rp = v3(sh.ray[0][owner], sh.ray[1][owner], sh.ray[2][owner]);
-		V3 rd = v3(sh.ray[3][owner], sh.ray[4][owner], sh.ray[5][owner]);
+		id = (int)(entry & 0x7fffffu);
+		rp = v3(sh.ray[0][owner], sh.ray[1][owner], sh.ray[2][owner]);
+		rd = v3(sh.ray[3][owner], sh.ray[4][owner], sh.ray[5][owner]);
+	}
+	PT_TOCK(sh, 2, tc);
+	uint32_t lo = 0, hi = 0;
+	if(i < end) {
 		GeoRef g = { sc.geo, sc.n, id };
 		v4f p0 = g.plane(G_POS), p3 = g.plane(G_DIM);
-		float distance = intersect_kind<KIND>(g, p0, p3, rp, rd, pos, nrm);
+		lo = sc.obj_range[2 * id]; hi = sc.obj_range[2 * id + 1];     // wanted after a hit only; asked for now, with the record
+		distance = intersect_kind<KIND>(g, p0, p3, rp, rd, pos, nrm);
+	}
+	PT_TOCK(sh, 3, tc);
+	if(i < end) {
 		if(distance > 0) {
-			uint32_t lo = sc.obj_range[2 * id], hi = sc.obj_range[2 * id + 1];
-			int n = (int)sh.ncell[owner];
-			for(int o = 0; o < n; o++) {
-				uint32_t c = sh.cells[o][owner];
-				if(!range_has(lo, hi, c)) continue;
-				int cx = (int)(c & 1023), cy = (int)((c >> 10) & 1023), cz = (int)((c >> 20) & 1023);
-				V3 blo = v3((float)((cx + sc.grid.cmin[0]) * sc.grid.cs[0]), (float)((cy + sc.grid.cmin[1]) * sc.grid.cs[1]), (float)((cz + sc.grid.cmin[2]) * sc.grid.cs[2]));
-				V3 bhi = v3((float)((cx + 1 + sc.grid.cmin[0]) * sc.grid.cs[0]), (float)((cy + 1 + sc.grid.cmin[1]) * sc.grid.cs[1]), (float)((cz + 1 + sc.grid.cmin[2]) * sc.grid.cs[2]));
-				if(inside_box(pos, blo, bhi)) {
-					key = ((unsigned long long)o << 55) | ((unsigned long long)__float_as_uint(distance) << 23) | (unsigned long long)id;
-					break;
+			// The hit counts for the first recorded cell that lists the entity and whose box holds the
+			// hit point, bounds included (code/raycast.cpp:957-983, pointInBox).  Per axis at most three
+			// cells around the point's quotient can hold it; the exact comparison against their bounds
+			// gives the interval of admissible cell coordinates, which is then cut to the entity's range.
+			int amin[3], amax[3];
+			const float pc[3] = { pos.x, pos.y, pos.z };
+			#pragma unroll
+			for(int a = 0; a < 3; a++) {
+				const int cs = sc.grid.cs[a], cmin = sc.grid.cmin[a];
+				const int guess = (int)floorf(pc[a] / (float)cs);
+				int first = 0x7fffffff, last = -0x7fffffff;
+				#pragma unroll
+				for(int dlt = -1; dlt <= 1; dlt++) {
+					const int cell = guess + dlt;
+					if(pc[a] >= (float)(cell * cs) && pc[a] <= (float)((cell + 1) * cs)) { first = imin(first, cell); last = imax(last, cell); }
 				}
+				amin[a] = imax(first - cmin, (int)((lo >> (10 * a)) & 1023u));
+				amax[a] = imin(last - cmin, (int)((hi >> (10 * a)) & 1023u));
 			}
+			const int n = (int)sh.ncell[owner];
+			int ordinal = -1;
+			#pragma unroll
+			for(int o = COOP_CELLS - 1; o >= 0; o--) {
+				const uint32_t c = sh.cells[o][owner];
+				const int cx = (int)(c & 1023u), cy = (int)((c >> 10) & 1023u), cz = (int)((c >> 20) & 1023u);
+				if(o < n && cx >= amin[0] && cx <= amax[0] && cy >= amin[1] && cy <= amax[1] && cz >= amin[2] && cz <= amax[2]) ordinal = o;
+			}
+			if(ordinal >= 0) key = ((unsigned long long)ordinal << 55) | ((unsigned long long)__float_as_uint(distance) << 23) | (unsigned long long)id;
 		}
 		if(key != COOP_NONE) { atomicMin(&sh.best[owner], key); PT_STAT(8, 1); }
 	}
+	PT_TOCK(sh, 4, tc);
 	wave_sync();
 	if(key != COOP_NONE && sh.best[owner] == key) {
 		sh.res[0][owner] = pos.x; sh.res[1][owner] = pos.y; sh.res[2][owner] = pos.z;
 		sh.res[3][owner] = nrm.x; sh.res[4][owner] = nrm.y; sh.res[5][owner] = nrm.z;
 	}
+	PT_TOCK(sh, 5, tc);
+#ifdef PT_COOP_TIMING
+	if(lane == 0) sh.tacc[6 + (KIND >= 3 ? 1 : 0) + (KIND >= 4 ? 1 : 0)] += 1;     // chunks: direct kinds, ellipsoid, cylinder/cone
+#endif
 }
 
 // Tests everything in the pool and empties it.  Whole wavefront.
@@ -770,7 +809,7 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 			if(i < total) {
 				uint32_t d = 0;
 				#pragma unroll
-				for(uint32_t step = 128; step >= 1; step >>= 1) {     // last descriptor that starts at or before i
+				for(uint32_t step = 256; step >= 1; step >>= 1) {     // last descriptor that starts at or before i
 					uint32_t t = d + step;
 					if(t < ndesc && sh.desc_start[t] <= i) d = t;
 				}

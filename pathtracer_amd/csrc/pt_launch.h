@@ -13,7 +13,6 @@ struct GridDev { int cmin[3], cnt[3], cs[3]; };
 
 struct SceneDev {
 	const float4* geo;
-	const float4* mat;
 	const uint32_t* cell_start;
 	const uint32_t* cell_items;
 	const float4* cell_entries; // cooperative cast: two float4 per cell_items entry (bounding sphere; entity, cell range)

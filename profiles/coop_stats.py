@@ -21,8 +21,12 @@ s = r.stats()
 names = ["", "segments", "chunks", "tests", "cells", "items", "deduped", "sphere_rejected", "accepted", "wave_casts"]
 casts = s.rays
 print(name, "casts", casts, "kernel_ms %.2f" % s.trace_ms)
-names += ["cyc_collect", "cyc_sort", "cyc_chunks", "cyc_verdict", "cyc_cast", "cyc_generate_shade"]
+names += ["cyc_walk", "cyc_expand", "cyc_drain", "cyc_verdict", "cyc_cast", "cyc_generate_shade"]
 print("  wave cycles total %d" % buf[0])
+tn = {2: "chunk_fetch", 3: "chunk_intersect", 4: "chunk_cellsearch", 5: "chunk_writeback"}
+for i in range(2, 6):
+    print(f"  {tn[i]:20s} {buf[i]:14d}  {100.0 * buf[i] / max(1, buf[0]):5.1f} % of wave time   per segment {buf[i] / max(1, buf[1]):8.0f}")
+print("  chunks direct/ellipsoid/cyl+cone", buf[6], buf[7], buf[8])
 for i in range(10, 16):
     print(f"  {names[i]:20s} {buf[i]:14d}  {100.0 * buf[i] / max(1, buf[0]):5.1f} % of wave time   per segment {buf[i] / max(1, buf[1]):8.0f}")
 for i in range(1, 10):
