@@ -186,15 +186,31 @@ int prepare(pt_ctx* c) {
 	bool coop = pt::object_ranges(rec.data(), n, gd, &ranges);
 	if((rc = upload(c, c->obj_range, ranges.data(), ranges.size() * 4))) return rc;
 	{
-		// the cooperative cast reads, per list entry, everything its collection step needs in one place
-		std::vector<float> entries(coop ? cell_items.size() * 8 : 8, 0.0f);
-		for(size_t k = 0; coop && k < cell_items.size(); k++) {
-			const uint32_t id = cell_items[k];
-			const float* r = rec.data() + (size_t)id * PT_F_STRIDE;
-			float* e = entries.data() + k * 8;
-			e[0] = r[PT_F_POS]; e[1] = r[PT_F_POS + 1]; e[2] = r[PT_F_POS + 2]; e[3] = r[PT_F_BRADIUS];
-			memcpy(e + 4, &id, 4);
-			memcpy(e + 5, &ranges[(size_t)id * 2], 8);
+		// What the cooperative cast's collection step needs of a list entry, in 16 bytes: the bounding
+		// sphere (radius rounded up to its upper 16 bits), in which of the six neighbour cells the
+		// entity is listed as well (bits 3..8: -x +x -y +y -z +z), and its intersection kind (bits 0..2).
+		std::vector<float> entries(coop ? (cell_items.size() + 1) * 4 : 4, 0.0f);
+		const int64_t cells = coop ? gd.cells() : 0;
+		for(int64_t cell = 0; cell < cells; cell++) {
+			const uint32_t at[3] = { (uint32_t)(cell % gd.cell_count[0]), (uint32_t)((cell / gd.cell_count[0]) % gd.cell_count[1]),
+			                         (uint32_t)(cell / ((int64_t)gd.cell_count[0] * gd.cell_count[1])) };
+			for(uint32_t k = cell_start[(size_t)cell]; k < cell_start[(size_t)cell + 1]; k++) {
+				const uint32_t id = cell_items[k];
+				const float* r = rec.data() + (size_t)id * PT_F_STRIDE;
+				const uint32_t lo = ranges[(size_t)id * 2], hi = ranges[(size_t)id * 2 + 1];
+				uint32_t tag = (lo >> 30) | ((hi >> 30) << 2);
+				for(int a = 0; a < 3; a++) {
+					if(at[a] > ((lo >> (10 * a)) & 1023u)) tag |= 1u << (3 + 2 * a);
+					if(at[a] < ((hi >> (10 * a)) & 1023u)) tag |= 1u << (4 + 2 * a);
+				}
+				uint32_t radius;
+				memcpy(&radius, r + PT_F_BRADIUS, 4);
+				if(radius & 0xffffu) radius = (radius & 0xffff0000u) + 0x10000u;
+				tag |= radius;
+				float* e = entries.data() + (size_t)k * 4;
+				e[0] = r[PT_F_POS]; e[1] = r[PT_F_POS + 1]; e[2] = r[PT_F_POS + 2];
+				memcpy(e + 3, &tag, 4);
+			}
 		}
 		if((rc = upload(c, c->cell_entries, entries.data(), entries.size() * 4))) return rc;
 	}
@@ -229,7 +245,7 @@ int prepare(pt_ctx* c) {
 	j.scene.offsets = c->offsets.as<int32_t>();
 	j.scene.n = n;
 	j.scene.brute = n < s.brute_force_below ? 1 : 0;
-	for(int k = 0; k < 3; k++) { j.scene.grid.cmin[k] = gd.coord_min[k]; j.scene.grid.cnt[k] = gd.cell_count[k]; j.scene.grid.cs[k] = gd.cell_size[k]; }
+	for(int k = 0; k < 3; k++) { j.scene.grid.cmin[k] = gd.coord_min[k]; j.scene.grid.cnt[k] = gd.cell_count[k]; j.scene.grid.cs[k] = gd.cell_size[k]; j.scene.grid.inv_cs[k] = 1.0f / (float)gd.cell_size[k]; }
 
 	// per-job constants of the tile job (code/raycast.cpp:1010-1021), evaluated once on the host
 	ptl::FrameDev f{};

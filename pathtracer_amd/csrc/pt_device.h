@@ -34,7 +34,7 @@ struct Scene {
 	cf4 geo, dirs;
 	cf2 disc, samples;
 	cu32 cell_start, cell_items, obj_range;
-	cf4 entries;                 // per cell-list entry: {centre, bounding radius}, {entity, cell range lo, hi, 0}
+	cf4 entries;                 // per cell-list entry: bounding-sphere centre | radius (upper 16 bits, rounded up), listed-in-neighbour mask << 3, kind
 	ci32 offsets;
 	int n, brute;
 	Grid grid;
@@ -545,14 +545,18 @@ constexpr int COOP_CELLS = PT_COOP_CELLS;               // cells a lane records 
 constexpr int COOP_POOL = PT_COOP_POOL;                 // candidates awaiting their intersection test
 constexpr int COOP_DESCS = PT_COOP_DESCS;               // non-empty cells the wavefront can note per segment (at most 511)
 constexpr int COOP_MIN_WALKING = PT_COOP_MIN_WALKING;   // fewer walking lanes than this: return and refill
+#ifndef PT_COOP_ITEMS
+#define PT_COOP_ITEMS 2
+#endif
+constexpr int COOP_ITEMS = PT_COOP_ITEMS;                 // list entries a lane expands per trip
 constexpr uint64_t COOP_NONE = ~0ull;
 
 struct CoopShared {                           // one per wavefront
-	float ray[6][64];                         // origin, direction of each lane's ray
+	v2f ray[64][3];                           // origin, direction of each lane's ray (x y | z dx | dy dz)
 	uint32_t cells[COOP_CELLS][64];           // packed coordinates of the cells recorded this segment
-	uint32_t ncell[64];
+	uint8_t ncell[64];
 	unsigned long long best[64];              // winning key per ray
-	float res[6][64];                         // hit position, normal of the winner
+	v2f res[64][3];                           // hit position, normal of the winner, packed the same way
 	uint32_t pool[COOP_POOL];                 // candidates: owner lane << 26 | kind << 23 | entity
 	uint32_t sorted[COOP_POOL];               // the same, grouped by kind
 	uint32_t count[KIND_COUNT + 2];           // per kind, [KIND_COUNT] = total
@@ -560,7 +564,7 @@ struct CoopShared {                           // one per wavefront
 	unsigned long long work;                  // descriptors noted << 32 | list entries they cover
 	uint32_t desc_k0[COOP_DESCS];             // first entry of the cell's list
 	uint32_t desc_start[COOP_DESCS + 1];      // position of that entry in the flattened sequence
-	uint16_t desc_who[COOP_DESCS];            // owner lane | cell ordinal << 6
+	uint16_t desc_who[COOP_DESCS];            // owner lane | cell ordinal << 6 | face the ray entered through << 10 (7: none)
 #ifdef PT_COOP_TIMING
 	unsigned long long tacc[16];              // per-phase cycle sums of this wavefront
 #endif
@@ -599,6 +603,11 @@ PT_DEV bool range_has(uint32_t lo, uint32_t hi, uint32_t c) {
 	return cx >= (lo & 1023) && cx <= (hi & 1023) && cy >= ((lo >> 10) & 1023) && cy <= ((hi >> 10) & 1023) &&
 	       cz >= ((lo >> 20) & 1023) && cz <= ((hi >> 20) & 1023);
 }
+PT_DEV void put6(v2f (&slot)[3], V3 a, V3 b) { slot[0] = (v2f){ a.x, a.y }; slot[1] = (v2f){ a.z, b.x }; slot[2] = (v2f){ b.y, b.z }; }
+PT_DEV void get6(const v2f (&slot)[3], V3& a, V3& b) {
+	v2f u = slot[0], v = slot[1], w = slot[2];
+	a = v3(u.x, u.y, v.x); b = v3(v.y, w.x, w.y);
+}
 // Conservative reject: true when the ray's line misses the entity's (slightly enlarged) bounding
 // sphere or the sphere lies wholly behind the origin.  No exact intersector can report a hit then,
 // so skipping the entity does not change any result.  No divide, no square root.
@@ -631,8 +640,7 @@ PT_DEV void coop_chunk(const Scene& sc, CoopShared& sh, uint32_t base, uint32_t 
 		uint32_t entry = sh.sorted[i];
 		owner = (int)(entry >> 26);
 		id = (int)(entry & 0x7fffffu);
-		rp = v3(sh.ray[0][owner], sh.ray[1][owner], sh.ray[2][owner]);
-		rd = v3(sh.ray[3][owner], sh.ray[4][owner], sh.ray[5][owner]);
+		get6(sh.ray[owner], rp, rd);
 	}
 	PT_TOCK(sh, 2, tc);
 	uint32_t lo = 0, hi = 0;
@@ -653,16 +661,15 @@ PT_DEV void coop_chunk(const Scene& sc, CoopShared& sh, uint32_t base, uint32_t 
 			const float pc[3] = { pos.x, pos.y, pos.z };
 			#pragma unroll
 			for(int a = 0; a < 3; a++) {
+				// cell bounds are integers (coordinate * cell size), exact as floats, so the cells whose
+				// closed box holds the point are floor(p / size) and, when p sits on its lower bound, the one before
 				const int cs = sc.grid.cs[a], cmin = sc.grid.cmin[a];
-				const int guess = (int)floorf(pc[a] / (float)cs);
-				int first = 0x7fffffff, last = -0x7fffffff;
-				#pragma unroll
-				for(int dlt = -1; dlt <= 1; dlt++) {
-					const int cell = guess + dlt;
-					if(pc[a] >= (float)(cell * cs) && pc[a] <= (float)((cell + 1) * cs)) { first = imin(first, cell); last = imax(last, cell); }
-				}
+				int q = (int)floorf(pc[a] * sc.grid.inv_cs[a]);                // within one of the true quotient's floor
+				if((float)(q * cs) > pc[a]) q--;
+				else if((float)((q + 1) * cs) <= pc[a]) q++;
+				const int first = (float)(q * cs) == pc[a] ? q - 1 : q;
 				amin[a] = imax(first - cmin, (int)((lo >> (10 * a)) & 1023u));
-				amax[a] = imin(last - cmin, (int)((hi >> (10 * a)) & 1023u));
+				amax[a] = imin(q - cmin, (int)((hi >> (10 * a)) & 1023u));
 			}
 			const int n = (int)sh.ncell[owner];
 			int ordinal = -1;
@@ -678,10 +685,7 @@ PT_DEV void coop_chunk(const Scene& sc, CoopShared& sh, uint32_t base, uint32_t 
 	}
 	PT_TOCK(sh, 4, tc);
 	wave_sync();
-	if(key != COOP_NONE && sh.best[owner] == key) {
-		sh.res[0][owner] = pos.x; sh.res[1][owner] = pos.y; sh.res[2][owner] = pos.z;
-		sh.res[3][owner] = nrm.x; sh.res[4][owner] = nrm.y; sh.res[5][owner] = nrm.z;
-	}
+	if(key != COOP_NONE && sh.best[owner] == key) put6(sh.res[owner], pos, nrm);
 	PT_TOCK(sh, 5, tc);
 #ifdef PT_COOP_TIMING
 	if(lane == 0) sh.tacc[6 + (KIND >= 3 ? 1 : 0) + (KIND >= 4 ? 1 : 0)] += 1;     // chunks: direct kinds, ellipsoid, cylinder/cone
@@ -713,11 +717,14 @@ PT_DEV void coop_drain(const Scene& sc, CoopShared& sh, int lane) {
 	wave_sync();
 }
 
-// What a lane keeps of a cast between calls.
+// What a lane keeps of a cast between calls: the walker's cell, next-crossing parameters and their
+// increments.  Step signs come back from the ray's direction.
 struct CoopLane {
-	WalkLite w;
+	int cx, cy, cz;
+	float tx, ty, tz, dx, dy, dz;
 	bool walking;
 };
+PT_DEV int sign_of(float d) { return d == 0 ? 0 : (d > 0 ? 1 : -1); }
 PT_DEV void coop_lane_reset(CoopLane& st) { st.walking = false; }
 
 // All 64 lanes must call this together; `active` lanes own a ray, the others only lend a hand.
@@ -733,11 +740,12 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 		if(grid_entry(sc.grid, rp, rd, start)) {
 			Walk full;
 			walk_start(sc.grid, start, rd, full);
-			st.w = lite_of(full);
+			st.cx = full.cx; st.cy = full.cy; st.cz = full.cz;
+			st.tx = full.tx; st.ty = full.ty; st.tz = full.tz;
+			st.dx = full.dx; st.dy = full.dy; st.dz = full.dz;
 			st.walking = true;
 		}
-		sh.ray[0][lane] = rp.x; sh.ray[1][lane] = rp.y; sh.ray[2][lane] = rp.z;
-		sh.ray[3][lane] = rd.x; sh.ray[4][lane] = rd.y; sh.ray[5][lane] = rd.z;
+		put6(sh.ray[lane], rp, rd);
 	}
 	bool walking = active && st.walking;
 	int result = 0;
@@ -761,7 +769,14 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 		// all its cells are fetched in one memory round trip.
 		int recorded = 0, m = 0;
 		bool more = true;
-		WalkLite probe = st.w;
+		WalkLite probe;
+		probe.cx = st.cx; probe.cy = st.cy; probe.cz = st.cz; probe.tx = st.tx; probe.ty = st.ty; probe.tz = st.tz;
+		{
+			V3 from, dir;
+			get6(sh.ray[lane], from, dir);
+			probe.sx = sign_of(dir.x); probe.sy = sign_of(dir.y); probe.sz = sign_of(dir.z);
+			probe.dx = st.dx; probe.dy = st.dy; probe.dz = st.dz;
+		}
 		if(walking) {
 			int pc[COOP_CELLS];
 			uint32_t cc[COOP_CELLS], ka[COOP_CELLS], kb[COOP_CELLS];
@@ -772,14 +787,19 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 			}
 			#pragma unroll
 			for(int j = 0; j < COOP_CELLS; j++) { ka[j] = sc.cell_start[pc[j]]; kb[j] = sc.cell_start[pc[j] + 1]; }
+			// Descriptors are reserved cell by cell, all lanes in step, so that when they run out it is the
+			// far cells of every ray that wait for the next segment, not all cells of some rays.
+			uint32_t slot = 0, start = 0;
 			bool open = true;
 			#pragma unroll
 			for(int j = 0; j < COOP_CELLS; j++) {
 				if(j < m && open) {
 					uint32_t c = kb[j] - ka[j];
 					if(c > 0) {
-						unsigned long long old = atomicAdd(&sh.work, (1ull << 32) | (unsigned long long)c);
-						uint32_t slot = (uint32_t)(old >> 32), start = (uint32_t)old;
+						{
+							unsigned long long old = atomicAdd(&sh.work, (1ull << 32) | (unsigned long long)c);
+							slot = (uint32_t)(old >> 32); start = (uint32_t)old;
+						}
 						if(slot >= (uint32_t)COOP_DESCS) {
 							// no descriptor left this segment: this cell and the ones after it wait for the next
 							if(slot == (uint32_t)COOP_DESCS) sh.desc_start[COOP_DESCS] = start;
@@ -787,13 +807,19 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 						} else {
 							sh.desc_k0[slot] = ka[j];
 							sh.desc_start[slot] = start;
-							sh.desc_who[slot] = (uint16_t)((uint32_t)lane | ((uint32_t)j << 6));
+							// the face the ray came in through, from the coordinate that changed: -x +x -y +y -z +z
+							uint32_t face = 7;
+							if(j > 0) {
+								const int step = (int)cc[j] - (int)cc[j > 0 ? j - 1 : 0];
+								face = step == 1 ? 0u : step == -1 ? 1u : step == 1024 ? 2u : step == -1024 ? 3u : step > 0 ? 4u : 5u;
+							}
+							sh.desc_who[slot] = (uint16_t)((uint32_t)lane | ((uint32_t)j << 6) | (face << 10));
 						}
 					}
 					if(open) { sh.cells[j][lane] = cc[j]; recorded = j + 1; }
 				}
 			}
-			sh.ncell[lane] = (uint32_t)recorded;
+			sh.ncell[lane] = (uint8_t)recorded;
 			PT_STAT(4, recorded);
 		}
 		wave_sync();
@@ -804,40 +830,56 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 		const uint32_t noted = uniform((uint32_t)(work >> 32));
 		const uint32_t ndesc = noted < (uint32_t)COOP_DESCS ? noted : (uint32_t)COOP_DESCS;
 		const uint32_t total = uniform(noted > (uint32_t)COOP_DESCS ? sh.desc_start[COOP_DESCS] : (uint32_t)work);
-		for(uint32_t base = 0; base < total; base += 64) {
-			const uint32_t i = base + (uint32_t)lane;
-			if(i < total) {
-				uint32_t d = 0;
+		// search depth: the highest power of two below the number of descriptors (wave-uniform)
+		const uint32_t top = ndesc > 1 ? 1u << (31 - __builtin_clz(ndesc - 1)) : 0u;
+		for(uint32_t base = 0; base < total; base += 64 * COOP_ITEMS) {
+			// COOP_ITEMS independent items per lane and trip, so their LDS and memory round trips overlap
+			uint32_t item[COOP_ITEMS], d[COOP_ITEMS];
+			#pragma unroll
+			for(int u = 0; u < COOP_ITEMS; u++) { item[u] = base + (uint32_t)(u * 64 + lane); d[u] = 0; }
+			for(uint32_t step = top; step >= 1; step >>= 1) {     // last descriptor that starts at or before the item
 				#pragma unroll
-				for(uint32_t step = 256; step >= 1; step >>= 1) {     // last descriptor that starts at or before i
-					uint32_t t = d + step;
-					if(t < ndesc && sh.desc_start[t] <= i) d = t;
+				for(int u = 0; u < COOP_ITEMS; u++) {
+					uint32_t t = d[u] + step;
+					if(t < ndesc && sh.desc_start[t] <= item[u]) d[u] = t;
 				}
-				const uint32_t k = sh.desc_k0[d] + (i - sh.desc_start[d]);
-				const uint32_t who = sh.desc_who[d];
-				const int owner = (int)(who & 63u), ord = (int)(who >> 6);
-				const v4f e0 = sc.entries[2 * (size_t)k];
-				const v4f e1 = sc.entries[2 * (size_t)k + 1];
-				const uint32_t id = __float_as_uint(e1.x), lo = __float_as_uint(e1.y), hi = __float_as_uint(e1.z);
-				PT_STAT(5, 1);
-				// an entity that also lies in the ray's previous cell was collected there (the cells of a
-				// ray inside an entity's box-shaped range are consecutive)
-				bool dup = false;
-				if(ord > 0) dup = range_has(lo, hi, sh.cells[ord - 1][owner]);
-				if(dup) PT_STAT(6, 1);
-				if(!dup) {
-					V3 op = v3(sh.ray[0][owner], sh.ray[1][owner], sh.ray[2][owner]);
-					V3 od = v3(sh.ray[3][owner], sh.ray[4][owner], sh.ray[5][owner]);
-					if(!sphere_rejects(op, od, e0)) {
-						uint32_t kind = (lo >> 30) | ((hi >> 30) << 2);
-						uint32_t slot = atomicAdd(&sh.count[KIND_COUNT], 1u);
-						atomicAdd(&sh.count[kind], 1u);
-						sh.pool[slot] = ((uint32_t)owner << 26) | (kind << 23) | id;
-					} else PT_STAT(7, 1);
+			}
+			uint32_t who[COOP_ITEMS], id[COOP_ITEMS];
+			v4f e[COOP_ITEMS];
+			bool live[COOP_ITEMS];
+			#pragma unroll
+			for(int u = 0; u < COOP_ITEMS; u++) {
+				live[u] = item[u] < total;
+				const uint32_t k = live[u] ? sh.desc_k0[d[u]] + (item[u] - sh.desc_start[d[u]]) : 0u;
+				who[u] = sh.desc_who[d[u]];
+				e[u] = sc.entries[k];
+				id[u] = sc.cell_items[k];
+			}
+			#pragma unroll
+			for(int u = 0; u < COOP_ITEMS; u++) {
+				if(live[u]) {
+					const int owner = (int)(who[u] & 63u);
+					const uint32_t tag = __float_as_uint(e[u].w);
+					PT_STAT(5, 1);
+					// an entity that is also listed in the cell the ray came from was collected there
+					const bool dup = ((tag >> 3) >> (who[u] >> 10)) & 1u;        // face 7 (no previous cell) reads a zero bit
+					if(dup) PT_STAT(6, 1);
+					if(!dup) {
+						V3 op, od;
+						get6(sh.ray[owner], op, od);
+						v4f ball = e[u];
+						ball.w = __uint_as_float(tag & 0xffff0000u);
+						if(!sphere_rejects(op, od, ball)) {
+							uint32_t kind = tag & 7u;
+							uint32_t slot = atomicAdd(&sh.count[KIND_COUNT], 1u);
+							atomicAdd(&sh.count[kind], 1u);
+							sh.pool[slot] = ((uint32_t)owner << 26) | (kind << 23) | id[u];
+						} else PT_STAT(7, 1);
+					}
 				}
 			}
 			wave_sync();
-			if(uniform(sh.count[KIND_COUNT]) > (uint32_t)(COOP_POOL - 64)) {
+			if(uniform(sh.count[KIND_COUNT]) > (uint32_t)(COOP_POOL - 64 * COOP_ITEMS)) {
 				PT_TOCK(sh, 11, t0);
 				coop_drain(sc, sh, lane);
 				PT_TOCK(sh, 12, t0);
@@ -854,15 +896,16 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 			unsigned long long key = recorded > 0 ? sh.best[lane] : COOP_NONE;
 			if(key != COOP_NONE) {
 				result = (int)(key & 0x7fffffu) + 1;
-				hpos = v3(sh.res[0][lane], sh.res[1][lane], sh.res[2][lane]);
-				hnrm = v3(sh.res[3][lane], sh.res[4][lane], sh.res[5][lane]);
+				get6(sh.res[lane], hpos, hnrm);
 				walking = false;
 			} else if(recorded == m) {
-				if(more) st.w = probe;       // the probe stands on the first cell of the next segment
-				else walking = false;        // the ray has left the grid
+				if(!more) walking = false;   // the ray has left the grid; else the probe stands on the first cell of the next segment
 			} else {
-				for(int j = 0; j < recorded; j++) lite_next(sc.grid, st.w);   // stopped early: resume at the first cell not recorded
+				// stopped early: resume at the first cell not recorded
+				probe.cx = st.cx; probe.cy = st.cy; probe.cz = st.cz; probe.tx = st.tx; probe.ty = st.ty; probe.tz = st.tz;
+				for(int j = 0; j < recorded; j++) lite_next(sc.grid, probe);
 			}
+			st.cx = probe.cx; st.cy = probe.cy; st.cz = probe.cz; st.tx = probe.tx; st.ty = probe.ty; st.tz = probe.tz;
 		}
 		PT_TOCK(sh, 13, t0);
 		if(__popcll(__ballot(walking)) < COOP_MIN_WALKING) break;

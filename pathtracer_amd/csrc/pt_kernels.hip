@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 						if(job.frame_index < 0) { si = 0; si_end = n_samples; pass = 0; }
 						else { si = job.frame_index % n_samples; si_end = si + 1; pass = (uint64_t)(job.frame_index / n_samples); }
 						lens = fr->aperture != 0.0f ? lens_start(fr, px, py) : 0;
-						origin = pixel_origin(fr, px, py);
+						if(MODE != CAST_GRID_COOP) origin = pixel_origin(fr, px, py);
 						sum = v3(0, 0, 0);
 						state = NEED_PATH;
 					}
@@ -124,8 +124,11 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 		// ---- stage 1: generate the camera ray of the next sample (code/raycast.cpp:1059-1090) ---
 		if(state == NEED_PATH) {
 			v2f s = sc.samples[sample_base + si];
-			camera_ray(sc, fr, origin, s, lens + si, rp, rd);
-			sample_stream(fr, px, py, si, pass, rng);
+			// the cooperative cast is short of registers: it recomputes what the other variants keep per pixel
+			const V3 from = MODE == CAST_GRID_COOP ? pixel_origin(fr, px, py) : origin;
+			const uint64_t round = MODE == CAST_GRID_COOP ? (job.frame_index < 0 ? 0ull : (uint64_t)(job.frame_index / n_samples)) : pass;
+			camera_ray(sc, fr, from, s, lens + si, rp, rd);
+			sample_stream(fr, px, py, si, round, rng);
 			att = v3(1, 1, 1);
 			col = v3(0, 0, 0);
 			bounce = 0;
@@ -144,6 +147,7 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 			// the whole wavefront takes part; lanes whose walk is not over yet stay in flight and resume
 			id = cast_grid_coop(sc, coop, lane, flying, fresh, walk_state, rp, rd, hp, hn, surf, landed);
 			fresh = landed || !flying;
+			get6(coop.ray[lane], rp, rd);     // the ray waits in LDS during the cast, not in registers
 			PT_TOCK(coop, 14, t_loop);
 		} else if(flying) {
 			uint64_t unused = 0;

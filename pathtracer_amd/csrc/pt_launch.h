@@ -9,13 +9,13 @@ namespace ptl {
 // does not need to include device code.
 struct Vec { float x, y, z; };
 
-struct GridDev { int cmin[3], cnt[3], cs[3]; };
+struct GridDev { int cmin[3], cnt[3], cs[3]; float inv_cs[3]; };
 
 struct SceneDev {
 	const float4* geo;
 	const uint32_t* cell_start;
 	const uint32_t* cell_items;
-	const float4* cell_entries; // cooperative cast: two float4 per cell_items entry (bounding sphere; entity, cell range)
+	const float4* cell_entries; // cooperative cast: one float4 per cell_items entry (bounding sphere, neighbour mask, kind)
 	const uint32_t* obj_range;  // per entity: inclusive cell range, 10 bits per axis, and its intersection kind (2 words)
 	const float4* dirs;
 	const float2* disc;
