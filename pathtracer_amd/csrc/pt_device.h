@@ -530,17 +530,17 @@ PT_DEV int cast(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface& surf
 // code/raycast.cpp:957-983) is restored exactly by a 64-bit key (cell ordinal | distance bits | id)
 // reduced with an LDS atomic min per ray.
 #ifndef PT_COOP_CELLS
-#define PT_COOP_CELLS 8
+#define PT_COOP_CELLS 6
 #endif
 #ifndef PT_COOP_MIN_WALKING
-#define PT_COOP_MIN_WALKING 56
+#define PT_COOP_MIN_WALKING 48
 #endif
 constexpr int COOP_CELLS = PT_COOP_CELLS;               // cells a lane records per segment
 #ifndef PT_COOP_POOL
 #define PT_COOP_POOL 256
 #endif
 #ifndef PT_COOP_DESCS
-#define PT_COOP_DESCS 192
+#define PT_COOP_DESCS 360
 #endif
 constexpr int COOP_POOL = PT_COOP_POOL;                 // candidates awaiting their intersection test
 constexpr int COOP_DESCS = PT_COOP_DESCS;               // non-empty cells the wavefront can note per segment (at most 511)
@@ -549,6 +549,8 @@ constexpr int COOP_MIN_WALKING = PT_COOP_MIN_WALKING;   // fewer walking lanes t
 #define PT_COOP_ITEMS 2
 #endif
 constexpr int COOP_ITEMS = PT_COOP_ITEMS;                 // list entries a lane expands per trip
+constexpr uint32_t COOP_SEQ_MAX = 1u << 20;                // list entries one segment can hold (20 bits of desc_at)
+static_assert(PT_COOP_CELLS <= 8, "the cell ordinal has three bits in a descriptor");
 constexpr uint64_t COOP_NONE = ~0ull;
 
 struct CoopShared {                           // one per wavefront
@@ -562,9 +564,10 @@ struct CoopShared {                           // one per wavefront
 	uint32_t count[KIND_COUNT + 2];           // per kind, [KIND_COUNT] = total
 	uint32_t fill[KIND_COUNT + 2];
 	unsigned long long work;                  // descriptors noted << 32 | list entries they cover
+	unsigned long long cutoff;                // first descriptor turned away << 32 | its sequence position
 	uint32_t desc_k0[COOP_DESCS];             // first entry of the cell's list
-	uint32_t desc_start[COOP_DESCS + 1];      // position of that entry in the flattened sequence
-	uint16_t desc_who[COOP_DESCS];            // owner lane | cell ordinal << 6 | face the ray entered through << 10 (7: none)
+	uint32_t desc_at[COOP_DESCS];             // position of that entry in the flattened sequence << 12 |
+	                                          // owner lane | cell ordinal << 6 | face the ray entered through << 9 (7: none)
 #ifdef PT_COOP_TIMING
 	unsigned long long tacc[16];              // per-phase cycle sums of this wavefront
 #endif
@@ -759,7 +762,7 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 		PT_TICK(t0);
 		// ---- reset the wavefront's bins --------------------------------------------------------
 		if(lane < KIND_COUNT + 2) { sh.count[lane] = 0; sh.fill[lane] = 0; }
-		if(lane == 0) sh.work = 0;
+		if(lane == 0) { sh.work = 0; sh.cutoff = COOP_NONE; }
 		sh.best[lane] = COOP_NONE;
 		sh.ncell[lane] = 0;
 		wave_sync();
@@ -800,20 +803,20 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 							unsigned long long old = atomicAdd(&sh.work, (1ull << 32) | (unsigned long long)c);
 							slot = (uint32_t)(old >> 32); start = (uint32_t)old;
 						}
-						if(slot >= (uint32_t)COOP_DESCS) {
-							// no descriptor left this segment: this cell and the ones after it wait for the next
-							if(slot == (uint32_t)COOP_DESCS) sh.desc_start[COOP_DESCS] = start;
+						if(slot >= (uint32_t)COOP_DESCS || (start > 0 && start + c > COOP_SEQ_MAX)) {
+							// no room left this segment: this cell and the ones after it wait for the next.  Slots
+							// and positions grow together, so everything reserved after the first refusal is refused too.
+							atomicMin(&sh.cutoff, ((unsigned long long)slot << 32) | (unsigned long long)start);
 							open = false;
 						} else {
 							sh.desc_k0[slot] = ka[j];
-							sh.desc_start[slot] = start;
 							// the face the ray came in through, from the coordinate that changed: -x +x -y +y -z +z
 							uint32_t face = 7;
 							if(j > 0) {
 								const int step = (int)cc[j] - (int)cc[j > 0 ? j - 1 : 0];
 								face = step == 1 ? 0u : step == -1 ? 1u : step == 1024 ? 2u : step == -1024 ? 3u : step > 0 ? 4u : 5u;
 							}
-							sh.desc_who[slot] = (uint16_t)((uint32_t)lane | ((uint32_t)j << 6) | (face << 10));
+							sh.desc_at[slot] = (start << 12) | (uint32_t)lane | ((uint32_t)j << 6) | (face << 9);
 						}
 					}
 					if(open) { sh.cells[j][lane] = cc[j]; recorded = j + 1; }
@@ -828,8 +831,10 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 		// ---- expand: the lists of all lanes as one sequence, 64 entries per round ------------------
 		const unsigned long long work = sh.work;
 		const uint32_t noted = uniform((uint32_t)(work >> 32));
-		const uint32_t ndesc = noted < (uint32_t)COOP_DESCS ? noted : (uint32_t)COOP_DESCS;
-		const uint32_t total = uniform(noted > (uint32_t)COOP_DESCS ? sh.desc_start[COOP_DESCS] : (uint32_t)work);
+		const unsigned long long cutoff = sh.cutoff;
+		const uint32_t refused = uniform((uint32_t)(cutoff >> 32));
+		const uint32_t ndesc = noted < refused ? noted : refused;
+		const uint32_t total = uniform(cutoff != COOP_NONE ? (uint32_t)cutoff : (uint32_t)work);
 		// search depth: the highest power of two below the number of descriptors (wave-uniform)
 		const uint32_t top = ndesc > 1 ? 1u << (31 - __builtin_clz(ndesc - 1)) : 0u;
 		for(uint32_t base = 0; base < total; base += 64 * COOP_ITEMS) {
@@ -841,7 +846,7 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 				#pragma unroll
 				for(int u = 0; u < COOP_ITEMS; u++) {
 					uint32_t t = d[u] + step;
-					if(t < ndesc && sh.desc_start[t] <= item[u]) d[u] = t;
+					if(t < ndesc && (sh.desc_at[t] >> 12) <= item[u]) d[u] = t;
 				}
 			}
 			uint32_t who[COOP_ITEMS], id[COOP_ITEMS];
@@ -850,8 +855,8 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 			#pragma unroll
 			for(int u = 0; u < COOP_ITEMS; u++) {
 				live[u] = item[u] < total;
-				const uint32_t k = live[u] ? sh.desc_k0[d[u]] + (item[u] - sh.desc_start[d[u]]) : 0u;
-				who[u] = sh.desc_who[d[u]];
+				who[u] = sh.desc_at[d[u]];
+				const uint32_t k = live[u] ? sh.desc_k0[d[u]] + (item[u] - (who[u] >> 12)) : 0u;
 				e[u] = sc.entries[k];
 				id[u] = sc.cell_items[k];
 			}
@@ -862,7 +867,7 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 					const uint32_t tag = __float_as_uint(e[u].w);
 					PT_STAT(5, 1);
 					// an entity that is also listed in the cell the ray came from was collected there
-					const bool dup = ((tag >> 3) >> (who[u] >> 10)) & 1u;        // face 7 (no previous cell) reads a zero bit
+					const bool dup = ((tag >> 3) >> ((who[u] >> 9) & 7u)) & 1u;        // face 7 (no previous cell) reads a zero bit
 					if(dup) PT_STAT(6, 1);
 					if(!dup) {
 						V3 op, od;
