@@ -332,6 +332,54 @@ PT_DEV float intersect_kind(const GeoRef& g, v4f p0, v4f p3, V3 rp, V3 rd, V3& p
 	return distance;
 }
 
+// All six kinds in one body, for a wavefront whose lanes hold candidates of different kinds: the
+// kinds that work in the entity's unit space (rotated box, ellipsoid, cylinder, cone) share the
+// transformation in and out, which is most of their cost; only the canonical-shape test in the
+// middle diverges.  Every lane runs exactly the operation sequence of its intersect_kind variant.
+constexpr int KIND_MIXED = KIND_COUNT;
+PT_DEV float intersect_mixed(int kind, const GeoRef& g, v4f p0, v4f p3, V3 rp, V3 rd, V3& pos, V3& nrm) {
+	V3 opos = v3(p0.x, p0.y, p0.z);
+	V3 dim = v3(p3.x, p3.y, p3.z);
+	if(kind == KIND_SPHERE) return hit_sphere(rp, rd, opos, dim.x * 0.5f, pos, nrm);
+	if(kind == KIND_BOX) return hit_box(rp, rd, opos, dim, pos, nrm);
+	const bool isbox = kind == KIND_BOX_ROTATED;
+	const bool turned = isbox || ((__float_as_int(p3.w) >> 8) & FLAG_ROTATED);
+	v4f si = g.plane(G_SCALEINV);
+	V3 sinv = v3(si.x, si.y, si.z);
+	V3 a = rp - opos;
+	V3 b = isbox ? a + rd : rd;
+	if(turned) {
+		v4f ri = g.plane(G_ROTINV);
+		a = rotate(ri, a);
+		b = rotate(ri, b);
+	}
+	V3 din;
+	if(isbox) din = b - a;
+	else { a = a * sinv; din = b * sinv; }
+	V3 ld = normalise(din);
+	float distance;
+	if(isbox) distance = hit_box(a, ld, v3(0, 0, 0), dim, pos, nrm);
+	else if(kind == KIND_ELLIPSOID) distance = hit_sphere(a, ld, v3(0, 0, 0), 0.5f, pos, nrm);
+	else if(kind == KIND_CYLINDER) distance = hit_cylinder(a, ld, pos, nrm);
+	else distance = hit_cone(a, ld, pos, nrm);
+	if(distance != -1) {
+		if(!isbox) {
+			v4f sc4 = g.plane(G_SCALE);
+			pos = pos * v3(sc4.x, sc4.y, sc4.z);
+			nrm = nrm * sinv;
+		}
+		if(turned) {
+			v4f r = g.plane(G_ROT);
+			pos = rotate(r, pos);
+			nrm = rotate(r, nrm);
+		}
+		pos = pos + opos;
+		if(!isbox) nrm = normalise(nrm);
+		distance = length(rp - pos);
+	}
+	return distance;
+}
+
 // getIntersection (code/raycast.cpp:813-893).  p0 = plane G_POS already loaded by the caller.
 PT_DEV float intersect(const GeoRef& g, v4f p0, V3 rp, V3 rd, V3& pos, V3& nrm) {
 	v4f p3 = g.plane(G_DIM);
@@ -551,6 +599,14 @@ constexpr int COOP_MIN_WALKING = PT_COOP_MIN_WALKING;   // fewer walking lanes t
 constexpr int COOP_ITEMS = PT_COOP_ITEMS;                 // list entries a lane expands per trip
 constexpr uint32_t COOP_SEQ_MAX = 1u << 20;                // list entries one segment can hold (20 bits of desc_at)
 static_assert(PT_COOP_CELLS <= 8, "the cell ordinal has three bits in a descriptor");
+#ifndef PT_COOP_MIX_ALL
+#define PT_COOP_MIX_ALL 128
+#endif
+#ifndef PT_COOP_MIX_UNIT
+#define PT_COOP_MIX_UNIT 128
+#endif
+constexpr int COOP_MIX_ALL = PT_COOP_MIX_ALL;     // at most this many candidates in all: chunks of mixed kinds
+constexpr int COOP_MIX_UNIT = PT_COOP_MIX_UNIT;   // at most this many unit-space candidates: mixed chunks for them
 constexpr uint64_t COOP_NONE = ~0ull;
 
 struct CoopShared {                           // one per wavefront
@@ -637,12 +693,13 @@ PT_DEV void coop_chunk(const Scene& sc, CoopShared& sh, uint32_t base, uint32_t 
 	V3 pos = v3(0, 0, 0), nrm = v3(0, 0, 0);
 	PT_TICK(tc);
 	float distance = -1;
-	int id = 0;
+	int id = 0, mixed_kind = 0;
 	V3 rp = v3(0, 0, 0), rd = v3(0, 0, 1);
 	if(i < end) {
 		uint32_t entry = sh.sorted[i];
 		owner = (int)(entry >> 26);
 		id = (int)(entry & 0x7fffffu);
+		mixed_kind = (int)((entry >> 23) & 7u);
 		get6(sh.ray[owner], rp, rd);
 	}
 	PT_TOCK(sh, 2, tc);
@@ -651,7 +708,7 @@ PT_DEV void coop_chunk(const Scene& sc, CoopShared& sh, uint32_t base, uint32_t 
 		GeoRef g = { sc.geo, sc.n, id };
 		v4f p0 = g.plane(G_POS), p3 = g.plane(G_DIM);
 		lo = sc.obj_range[2 * id]; hi = sc.obj_range[2 * id + 1];     // wanted after a hit only; asked for now, with the record
-		distance = intersect_kind<KIND>(g, p0, p3, rp, rd, pos, nrm);
+		distance = KIND == KIND_MIXED ? intersect_mixed(mixed_kind, g, p0, p3, rp, rd, pos, nrm) : intersect_kind<KIND>(g, p0, p3, rp, rd, pos, nrm);
 	}
 	PT_TOCK(sh, 3, tc);
 	if(i < end) {
@@ -691,7 +748,7 @@ PT_DEV void coop_chunk(const Scene& sc, CoopShared& sh, uint32_t base, uint32_t 
 	if(key != COOP_NONE && sh.best[owner] == key) put6(sh.res[owner], pos, nrm);
 	PT_TOCK(sh, 5, tc);
 #ifdef PT_COOP_TIMING
-	if(lane == 0) sh.tacc[6 + (KIND >= 3 ? 1 : 0) + (KIND >= 4 ? 1 : 0)] += 1;     // chunks: direct kinds, ellipsoid, cylinder/cone
+	if(lane == 0) sh.tacc[KIND == KIND_MIXED ? 9 : 6 + (KIND >= 3 ? 1 : 0) + (KIND >= 4 ? 1 : 0)] += 1;     // chunks: direct kinds, ellipsoid, cylinder/cone, mixed
 #endif
 }
 
@@ -710,12 +767,21 @@ PT_DEV void coop_drain(const Scene& sc, CoopShared& sh, int lane) {
 		sh.sorted[base + atomicAdd(&sh.fill[kind], 1u)] = e;
 	}
 	wave_sync();
-	for(uint32_t base = off[0]; base < off[1]; base += 64) coop_chunk<KIND_SPHERE>(sc, sh, base, off[1], lane);
-	for(uint32_t base = off[1]; base < off[2]; base += 64) coop_chunk<KIND_BOX>(sc, sh, base, off[2], lane);
-	for(uint32_t base = off[2]; base < off[3]; base += 64) coop_chunk<KIND_BOX_ROTATED>(sc, sh, base, off[3], lane);
-	for(uint32_t base = off[3]; base < off[4]; base += 64) coop_chunk<KIND_ELLIPSOID>(sc, sh, base, off[4], lane);
-	for(uint32_t base = off[4]; base < off[5]; base += 64) coop_chunk<KIND_CYLINDER>(sc, sh, base, off[5], lane);
-	for(uint32_t base = off[5]; base < off[6]; base += 64) coop_chunk<KIND_CONE>(sc, sh, base, off[6], lane);
+	// Few candidates: one chunk of mixed kinds costs less than a nearly empty chunk per kind.
+	if(total <= (uint32_t)COOP_MIX_ALL) {
+		for(uint32_t base = 0; base < total; base += 64) coop_chunk<KIND_MIXED>(sc, sh, base, total, lane);
+	} else {
+		for(uint32_t base = off[0]; base < off[1]; base += 64) coop_chunk<KIND_SPHERE>(sc, sh, base, off[1], lane);
+		for(uint32_t base = off[1]; base < off[2]; base += 64) coop_chunk<KIND_BOX>(sc, sh, base, off[2], lane);
+		if(off[6] - off[2] <= (uint32_t)COOP_MIX_UNIT) {
+			for(uint32_t base = off[2]; base < off[6]; base += 64) coop_chunk<KIND_MIXED>(sc, sh, base, off[6], lane);
+		} else {
+			for(uint32_t base = off[2]; base < off[3]; base += 64) coop_chunk<KIND_BOX_ROTATED>(sc, sh, base, off[3], lane);
+			for(uint32_t base = off[3]; base < off[4]; base += 64) coop_chunk<KIND_ELLIPSOID>(sc, sh, base, off[4], lane);
+			for(uint32_t base = off[4]; base < off[5]; base += 64) coop_chunk<KIND_CYLINDER>(sc, sh, base, off[5], lane);
+			for(uint32_t base = off[5]; base < off[6]; base += 64) coop_chunk<KIND_CONE>(sc, sh, base, off[6], lane);
+		}
+	}
 	if(lane < KIND_COUNT + 2) { sh.count[lane] = 0; sh.fill[lane] = 0; }
 	wave_sync();
 }
