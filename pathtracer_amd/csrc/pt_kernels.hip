@@ -37,15 +37,22 @@ enum { NEED_PIXEL = 0, NEED_PATH = 1, IN_FLIGHT = 2, RETIRED = 3 };
 enum { CAST_BRUTE = 0, CAST_GRID_LANE = 1, CAST_GRID_COOP = 2 };
 template <int MODE>
 __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(ptl::TraceJob job) {
-	__shared__ __attribute__((aligned(16))) char lds_raw[MODE == CAST_GRID_COOP ? sizeof(CoopShared) * (kBlock / 64) : 16];
-	CoopShared& coop = reinterpret_cast<CoopShared*>(lds_raw)[MODE == CAST_GRID_COOP ? threadIdx.x / 64 : 0];
+#ifdef PT_COOP_TIMING
+	constexpr bool kWaveLds = true;           // the phase timers live in the per-wave LDS block
+#else
+	constexpr bool kWaveLds = MODE == CAST_GRID_COOP;
+#endif
+	__shared__ __attribute__((aligned(16))) char lds_raw[kWaveLds ? sizeof(CoopShared) * (kBlock / 64) : 16];
+	CoopShared& coop = reinterpret_cast<CoopShared*>(lds_raw)[kWaveLds ? threadIdx.x / 64 : 0];
 	const Scene sc = scene_view(job.scene);
 	const FrameRef fr = (FrameRef)job.frame;
 	const int lane = lane_id();
 	const int width = fr->width, height = fr->height, tile_w = fr->tile_w, max_bounces = fr->max_bounces;
 
-	// wave-uniform tile pool
-	int pool_next = 0, pool_end = 0;
+	// wave-uniform tile pool: one 8x8 image tile at a time, with what all its pixels share
+	int pool_pos = kGroup;                   // next pixel of the tile to hand out; kGroup: tile used up
+	int tile_x0 = 0, tile_y0 = 0, tile_slot0 = 0, tile_mx = 0, tile_my = 0;
+	const int mod_magic = 65536 / tile_w + 1;   // v % tile_w for v < 16 and tile_w <= 4 without a division
 	bool dry = false;
 
 	// per-lane pixel state
@@ -71,9 +78,11 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 
 	for(;;) {
 		// ---- stage 0: lanes without a pixel draw one from the wave's pool -------------------
+		// (Making lanes wait until several ask together was measured: the idle lanes cost more than
+		// the hand-outs saved.)
 		uint64_t want = __ballot(state == NEED_PIXEL);
 		while(want != 0) {
-			if(pool_next == pool_end) {
+			if(pool_pos == kGroup) {
 				if(dry) break;
 				uint32_t g = 0, stop = 0;
 				if(lane == 0) {
@@ -83,20 +92,25 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 				g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
 				stop = (uint32_t)__builtin_amdgcn_readfirstlane((int)stop);
 				if(stop != 0 || g >= (uint32_t)job.n_groups) { dry = true; break; }
-				pool_next = (int)g * kGroup;
-				pool_end = pool_next + kGroup;
+				const int tile = (int)g * job.part_count + job.part_index;
+				tile_x0 = (tile % job.tiles_x) * 8;
+				tile_y0 = (tile / job.tiles_x) * 8;
+				tile_slot0 = (int)g * kGroup;
+				tile_mx = tile_x0 % tile_w;
+				tile_my = tile_y0 % tile_w;
+				pool_pos = 0;
 			}
-			int avail = pool_end - pool_next;
+			int avail = kGroup - pool_pos;
 			int rank = lanes_below(want);
 			if(state == NEED_PIXEL && rank < avail) {
-				int slot = pool_next + rank;
-				int local_tile = slot / kGroup, j = slot % kGroup;
-				int tile = local_tile * job.part_count + job.part_index;
-				px = (tile % job.tiles_x) * 8 + (j & 7);
-				py = (tile / job.tiles_x) * 8 + (j >> 3);
+				const int j = pool_pos + rank;
+				px = tile_x0 + (j & 7);
+				py = tile_y0 + (j >> 3);
 				if(px < width && py < height) {
-					out_index = job.compact ? (size_t)slot : (size_t)py * (size_t)width + (size_t)px;
-					int t = (py % tile_w) * tile_w + (px % tile_w);
+					out_index = job.compact ? (size_t)(tile_slot0 + j) : (size_t)py * (size_t)width + (size_t)px;
+					const int vx = tile_mx + (j & 7), vy = tile_my + (j >> 3);
+					const int rx = vx - ((vx * mod_magic) >> 16) * tile_w, ry = vy - ((vy * mod_magic) >> 16) * tile_w;
+					int t = ry * tile_w + rx;                      // (py % tile_w) * tile_w + (px % tile_w)
 					sample_base = sc.offsets[t];
 					n_samples = sc.offsets[t + 1] - sample_base;
 					if(n_samples == 0) {
@@ -115,11 +129,12 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 				// pixels of an edge tile that fall outside the image are skipped: the lane asks again
 			}
 			int asked = __popcll(want);
-			pool_next += asked < avail ? asked : avail;
+			pool_pos += asked < avail ? asked : avail;
 			want = __ballot(state == NEED_PIXEL);
 		}
 		if(dry && state == NEED_PIXEL) state = RETIRED;
 		if(__ballot(state != RETIRED) == 0) break;
+		PT_TOCK(coop, MODE == CAST_GRID_COOP ? 15 : 10, t_loop);   // non-cooperative variants: slot 10 = pixel hand-out, 11 = camera ray, 14 = cast, 12 = shade and pixel write
 
 		// ---- stage 1: generate the camera ray of the next sample (code/raycast.cpp:1059-1090) ---
 		if(state == NEED_PATH) {
@@ -142,16 +157,19 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 		surf.m0 = (v4f)(0.0f); surf.m1 = (v4f){ 0.0f, 0.0f, 0.0f, 1.0f }; surf.rough = 0;
 		int id = 0;
 		bool landed = flying;
-		PT_TOCK(coop, 15, t_loop);
+		PT_TOCK(coop, MODE == CAST_GRID_COOP ? 15 : 11, t_loop);
 		if(MODE == CAST_GRID_COOP) {
 			// the whole wavefront takes part; lanes whose walk is not over yet stay in flight and resume
 			id = cast_grid_coop(sc, coop, lane, flying, fresh, walk_state, rp, rd, hp, hn, surf, landed);
 			fresh = landed || !flying;
 			get6(coop.ray[lane], rp, rd);     // the ray waits in LDS during the cast, not in registers
 			PT_TOCK(coop, 14, t_loop);
-		} else if(flying) {
-			uint64_t unused = 0;
-			id = MODE == CAST_BRUTE ? cast_all(sc, rp, rd, hp, hn, surf) : cast_grid<false>(sc, rp, rd, hp, hn, surf, unused);
+		} else {
+			if(flying) {
+				uint64_t unused = 0;
+				id = MODE == CAST_BRUTE ? cast_all(sc, rp, rd, hp, hn, surf) : cast_grid<false>(sc, rp, rd, hp, hn, surf, unused);
+			}
+			PT_TOCK(coop, 14, t_loop);
 		}
 		if(landed) {
 			casts++;
@@ -178,9 +196,10 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 				}
 			}
 		}
+		PT_TOCK(coop, MODE == CAST_GRID_COOP ? 15 : 12, t_loop);
 	}
 
-	PT_TOCK(coop, 15, t_loop);
+	PT_TOCK(coop, MODE == CAST_GRID_COOP ? 15 : 12, t_loop);
 	PT_TOCK(coop, 0, t_kernel);
 #ifdef PT_COOP_TIMING
 	if(lane == 0) for(int i = 0; i < 16; i++) PT_COUNT_(i, coop.tacc[i]);

@@ -21,7 +21,7 @@ s = r.stats()
 names = ["", "segments", "chunks", "tests", "cells", "items", "deduped", "sphere_rejected", "accepted", "wave_casts"]
 casts = s.rays
 print(name, "casts", casts, "kernel_ms %.2f" % s.trace_ms)
-names += ["cyc_walk", "cyc_expand", "cyc_drain", "cyc_verdict", "cyc_cast", "cyc_generate_shade"]
+names += ["cyc_walk|handout", "cyc_expand|camera", "cyc_drain|shade", "cyc_verdict", "cyc_cast", "cyc_generate_shade"]
 print("  wave cycles total %d" % buf[0])
 tn = {2: "chunk_fetch", 3: "chunk_intersect", 4: "chunk_cellsearch", 5: "chunk_writeback"}
 for i in range(2, 6):
