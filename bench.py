@@ -20,6 +20,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import re
 import sys
 import time
 
@@ -80,6 +81,10 @@ def workload(name):
     if name == "dense10k-1080p-16spp-d8":
         world, objs = scenes.dense_scene(n=10000, seed=4, half_extent=90.0, height=45.0)
         return world, objs, dict(width=1920, height=1080, spp=16, bounces=8, seed=12345, grid_hint=32)
+    m = re.fullmatch(r"demo-(\d+)x(\d+)-(\d+)spp-d(\d+)", name)
+    if m:                                   # the demo scene at any size, for scaling studies
+        world, objs = scenes.default_scene()
+        return world, objs, dict(width=int(m.group(1)), height=int(m.group(2)), spp=int(m.group(3)), bounces=int(m.group(4)), seed=12345)
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -130,6 +135,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="demo-1080p-64spp-d8")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--ranges", type=int, default=0, help="pt_settings.sample_ranges (0 = the library's choice)")
     args = ap.parse_args()
 
     import torch
@@ -146,6 +152,7 @@ def main():
 
     world, objs, kw = workload(args.workload)
     skw = dict(kw)
+    skw["sample_ranges"] = args.ranges
     st = api.default_settings(skw.pop("width"), skw.pop("height"), skw.pop("spp"), skw.pop("bounces"),
                               part_index=rank, part_count=world_size, **skw)
     r = api.Renderer(local_rank)

@@ -96,7 +96,11 @@ typedef struct pt_settings {
 	int32_t frame_index;         /* progressive mode: >= 0 traces ONE sample per pixel, sample
 	                                (frame_index mod count(tile)), and adds it into the accumulation
 	                                buffer; -1 = full render of every sample */
-	int32_t reserved;
+	int32_t sample_ranges;       /* a pixel's samples are summed in this many contiguous ranges (range r of n samples is
+	                                [r*n/ranges, (r+1)*n/ranges), each summed in sample order; the range sums are then added
+	                                in range order).  A power of two up to 16, or 0 = chosen from spp_wanted by
+	                                pt_sample_ranges().  The reference adds all samples in one sequence (= 1 range,
+	                                code/raycast.cpp:1263); more ranges only change the rounding of that sum. */
 } pt_settings;
 
 typedef struct pt_progress {
@@ -191,6 +195,11 @@ int pt_cast_rays(pt_ctx* ctx, const float* origins, const float* dirs, int n,
 /* Screenshot stage code/app.cpp:1536-1552: linear float -> sRGB OETF -> 8-bit, on the device
  * framebuffer of the last trace. rgb8 holds width*height*3 bytes. */
 int pt_present_srgb8(pt_ctx* ctx, uint8_t* rgb8);
+
+/* The range count a render uses: settings->sample_ranges, or for 0 the largest power of two not
+ * above spp_wanted / 32, within 1..8.  Progressive frames trace one sample per pixel: always 1.
+ * Negative on a bad value.  Pure arithmetic. */
+int pt_sample_ranges(const pt_settings* settings);
 
 /*
  * Multi-GPU: a context prepared with part_count > 1 renders the 8x8 image tiles t with

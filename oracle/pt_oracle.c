@@ -1043,8 +1043,22 @@ static inline void sample_stream(const pto_scene* s, int x, int y, int si, uint6
 	pcg_seed(r, s->st.seed + pass, wh + pix * PT_STREAM_STRIDE + (uint64_t)si);
 }
 
+/* Range count of a render under PT_SEED_PER_SAMPLE (include/pt_api.h, pt_settings.sample_ranges):
+ * the asked count, or for 0 the largest power of two not above spp_wanted / 32, within 1..8.  The
+ * reference itself adds all samples of a pixel in one sequence (code/raycast.cpp:1263). */
+static int sample_ranges(const pt_settings* st) {
+	if(st->frame_index >= 0) return 1;
+	if(st->sample_ranges > 0) return st->sample_ranges;
+	int ranges = 1;
+	while(ranges < 8 && ranges * 2 * 32 <= st->spp_wanted) ranges *= 2;
+	return ranges;
+}
+
 /* One pixel, all its samples. rng is the job's generator under PT_SEED_PER_JOB and scratch
- * otherwise. per_sample (optional) receives the unclamped radiance of every sample. */
+ * otherwise. per_sample (optional) receives the unclamped radiance of every sample.
+ * Under PT_SEED_PER_JOB the clamped sample colours are added in one sequence, as the reference
+ * does; under PT_SEED_PER_SAMPLE they are added range by range (range r of count samples is
+ * [r*count/ranges, (r+1)*count/ranges)) and the range sums are then added in range order. */
 static v3 trace_pixel(pto_scene* s, const frame_t* f, int x, int y, int policy, pcg32* rng, float* per_sample,
                       int* first_hit, uint64_t* first_hash) {
 	v3 cpp = pixel_pos(s, f, x, y);
@@ -1064,13 +1078,18 @@ static v3 trace_pixel(pto_scene* s, const frame_t* f, int x, int y, int policy, 
 	if(first_hit) *first_hit = -1;
 	if(first_hash) *first_hash = 0;
 	v3 pixel = V3(0, 0, 0);
-	for(int si = 0; si < count; si++) {
-		pcg32 sr;
-		pcg32* r = rng;
-		if(policy != PT_SEED_PER_JOB) { sample_stream(s, x, y, si, 0, &sr); r = &sr; }
-		v3 c = trace_sample(s, f, cpp, smp[si], lens + si, r, si == 0 ? first_hit : 0, si == 0 ? first_hash : 0);
-		if(per_sample) { per_sample[3 * si] = c.x; per_sample[3 * si + 1] = c.y; per_sample[3 * si + 2] = c.z; }
-		pixel = add(pixel, clamp_max3(c, 1));
+	const int ranges = policy == PT_SEED_PER_JOB ? 1 : sample_ranges(&s->st);
+	for(int range = 0; range < ranges; range++) {
+		v3 part = V3(0, 0, 0);
+		for(int si = range * count / ranges; si < (range + 1) * count / ranges; si++) {
+			pcg32 sr;
+			pcg32* r = rng;
+			if(policy != PT_SEED_PER_JOB) { sample_stream(s, x, y, si, 0, &sr); r = &sr; }
+			v3 c = trace_sample(s, f, cpp, smp[si], lens + si, r, si == 0 ? first_hit : 0, si == 0 ? first_hash : 0);
+			if(per_sample) { per_sample[3 * si] = c.x; per_sample[3 * si + 1] = c.y; per_sample[3 * si + 2] = c.z; }
+			part = add(part, clamp_max3(c, 1));
+		}
+		pixel = range == 0 ? part : add(pixel, part);
 	}
 	if(count == 0) return V3(0, 0, 0);
 	return clamp_max3(divs(pixel, (float)count), 1);

@@ -52,7 +52,7 @@ class pt_settings(C.Structure):
                 ("sample_grid_width", C.c_int32), ("max_bounces", C.c_int32),
                 ("grid_hint", C.c_int32), ("brute_force_below", C.c_int32),
                 ("seed_policy", C.c_int32), ("seed", C.c_uint64), ("part_index", C.c_int32),
-                ("part_count", C.c_int32), ("frame_index", C.c_int32), ("reserved", C.c_int32)]
+                ("part_count", C.c_int32), ("frame_index", C.c_int32), ("sample_ranges", C.c_int32)]
 
 
 class pt_progress(C.Structure):

@@ -4,6 +4,7 @@
 // without a working HIP device every entry point that renders returns PT_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cstdarg>
@@ -54,16 +55,17 @@ struct pt_ctx {
 	bool prepared = false;
 
 	// device-resident scene
-	DevBuf geo, cell_start, cell_items, cell_entries, obj_range, dirs, disc, samples, offsets, frame_dev, fb, accum, counter, stats_dev, scratch;
+	DevBuf geo, cell_start, cell_items, cell_entries, obj_range, partial, fracs, dirs, disc, samples, offsets, frame_dev, fb, accum, counter, stats_dev, scratch;
 	uint32_t* abort_flag = nullptr;      // host-pinned, read by the trace kernel
 	uint32_t* abort_flag_dev = nullptr;  // the same word as the device addresses it
 	uint32_t* counter_host = nullptr;    // host-pinned landing word for progress polls
 	ptl::TraceJob job{};
 	size_t fb_floats = 0;
+	uint32_t serial = 0;        // launch counter: marks the range sums each launch writes
 	int local_tiles = 0;
 
 	// launch bookkeeping
-	std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // events of launches not yet synchronised
+	std::vector<std::array<hipEvent_t, 3>> pending;   // events of launches not yet synchronised: start, trace done, resolve done
 	std::vector<hipEvent_t> event_pool;
 	double kernel_ms_sum = 0;
 	int kernel_launches = 0;
@@ -108,6 +110,7 @@ int validate(pt_ctx* c, const pt_world* w, const pt_object* objs, int n, const p
 	if(s->seed_policy != PT_SEED_PER_SAMPLE) return fail(c, PT_ERR_ARG, "the device path implements seed policy PT_SEED_PER_SAMPLE only");
 	if(s->part_count < 1 || s->part_index < 0 || s->part_index >= s->part_count) return fail(c, PT_ERR_ARG, "bad partition %d of %d", s->part_index, s->part_count);
 	if(s->frame_index < -1) return fail(c, PT_ERR_ARG, "frame_index must be >= -1");
+	if(pt_sample_ranges(s) < 0) return fail(c, PT_ERR_ARG, "sample_ranges must be 0 or a power of two up to 16, not %d", s->sample_ranges);
 	for(int i = 0; i < n; i++) {
 		if(objs[i].type < PT_GEOM_SPHERE || objs[i].type > PT_GEOM_CONE)
 			return fail(c, PT_ERR_ARG, "object %d: geometry type %d is not supported on the device (sphere, box, cylinder, cone)", i, objs[i].type);
@@ -229,6 +232,17 @@ int prepare(pt_ctx* c) {
 	if(s.frame_index >= 0) PT_HIP(c, c->accum.reserve(c->fb_floats * 4));
 	PT_HIP(c, c->counter.reserve(256));
 	PT_HIP(c, c->stats_dev.reserve(256));
+	// range sums of every pixel slot, and the quotients x/width, y/height (the divisions of code/raycast.cpp:1050)
+	const int sum_ranges = pt_sample_ranges(&s);
+	int ranges_log2 = 0;
+	while((1 << ranges_log2) < sum_ranges) ranges_log2++;
+	PT_HIP(c, c->partial.reserve((c->fb_floats / 3) * (size_t)sum_ranges * 16));
+	{
+		std::vector<float> fracs((size_t)s.width + (size_t)s.height);
+		for(int x = 0; x < s.width; x++) fracs[(size_t)x] = (float)x / (float)s.width;
+		for(int y = 0; y < s.height; y++) fracs[(size_t)s.width + (size_t)y] = (float)y / (float)s.height;
+		if((rc = upload(c, c->fracs, fracs.data(), fracs.size() * 4))) return rc;
+	}
 	PT_HIP(c, hipMemsetAsync(c->stats_dev.p, 0, 256, c->stream));
 
 	ptl::TraceJob& j = c->job;
@@ -270,13 +284,17 @@ int prepare(pt_ctx* c) {
 	if((rc = upload(c, c->frame_dev, &f, sizeof f))) return rc;
 	j.frame = c->frame_dev.as<ptl::FrameDev>();
 
+	j.partial = c->partial.as<float4>();
+	j.col_frac = c->fracs.as<float>();
+	j.row_frac = c->fracs.as<float>() + s.width;
+	j.ranges_log2 = ranges_log2;
 	j.fb = c->fb.as<float>();
 	j.accum = s.frame_index >= 0 ? c->accum.as<float>() : nullptr;
 	j.group_counter = c->counter.as<uint32_t>();
 	j.abort_flag = c->abort_flag_dev;
 	j.stats = c->stats_dev.as<uint64_t>();
 	j.tiles_x = tiles_x; j.tiles_y = tiles_y;
-	j.n_groups = c->local_tiles;
+	j.n_groups = c->local_tiles * sum_ranges;
 	j.part_index = s.part_index; j.part_count = s.part_count;
 	j.frame_index = s.frame_index;
 	j.compact = compact ? 1 : 0;
@@ -313,15 +331,19 @@ int trace(pt_ctx* c, float* d_rgb, hipStream_t stream, bool sync) {
 	ptl::TraceJob job = c->job;
 	if(d_rgb) job.fb = d_rgb;
 	hipStream_t s = stream ? stream : c->stream;
-	hipEvent_t e0 = take_event(c), e1 = take_event(c);
-	if(!e0 || !e1) return fail(c, PT_ERR_DEVICE, "hipEventCreate failed");
+	if(++c->serial == 0) c->serial = 1;
+	job.serial = c->serial;
+	hipEvent_t e0 = take_event(c), e1 = take_event(c), e2 = take_event(c);
+	if(!e0 || !e1 || !e2) return fail(c, PT_ERR_DEVICE, "hipEventCreate failed");
 	PT_HIP(c, hipEventRecord(e0, s));
 	int blocks = 0;
 	PT_HIP(c, ptl::launch_trace(job, s, &blocks));
 	PT_HIP(c, hipEventRecord(e1, s));
+	PT_HIP(c, ptl::launch_resolve(job, c->fb_floats / 3, s));
+	PT_HIP(c, hipEventRecord(e2, s));
 	{
 		std::lock_guard<std::mutex> l(c->mu);
-		c->pending.push_back({ e0, e1 });
+		c->pending.push_back({ e0, e1, e2 });
 		c->stats.bounce_passes = 1;
 	}
 	if(sync) {
@@ -332,25 +354,26 @@ int trace(pt_ctx* c, float* d_rgb, hipStream_t stream, bool sync) {
 
 // Folds the events of finished launches into the statistics. The caller has synchronised.
 int collect(pt_ctx* c) {
-	std::vector<std::pair<hipEvent_t, hipEvent_t>> pend;
+	std::vector<std::array<hipEvent_t, 3>> pend;
 	{ std::lock_guard<std::mutex> l(c->mu); pend.swap(c->pending); }
-	double sum = 0;
+	double sum = 0, whole = 0;
 	float lo = 3.4e38f, hi = 0;
 	for(auto& p : pend) {
-		float ms = 0;
-		PT_HIP(c, hipEventSynchronize(p.second));
-		PT_HIP(c, hipEventElapsedTime(&ms, p.first, p.second));
+		float ms = 0, both = 0;
+		PT_HIP(c, hipEventSynchronize(p[2]));
+		PT_HIP(c, hipEventElapsedTime(&ms, p[0], p[1]));       // the trace kernel (with its counter reset)
+		PT_HIP(c, hipEventElapsedTime(&both, p[0], p[2]));     // trace + resolve
 		sum += ms;
+		whole += both;
 		lo = ms < lo ? ms : lo;
 		hi = ms > hi ? ms : hi;
-		c->event_pool.push_back(p.first);
-		c->event_pool.push_back(p.second);
+		for(hipEvent_t e : p) c->event_pool.push_back(e);
 	}
 	if(!pend.empty()) {
 		c->kernel_ms_sum = sum;
 		c->kernel_launches = (int)pend.size();
-		c->stats.trace_ms = (float)(sum / pend.size());
-		c->stats.dominant_kernel_ms = c->stats.trace_ms;
+		c->stats.trace_ms = (float)(whole / pend.size());
+		c->stats.dominant_kernel_ms = (float)(sum / pend.size());
 		c->stats.trace_ms_min = lo; c->stats.trace_ms_max = hi; c->stats.trace_launches = (int)pend.size();
 		uint64_t rays = 0;
 		PT_HIP(c, hipMemcpy(&rays, c->stats_dev.p, sizeof rays, hipMemcpyDeviceToHost));
@@ -430,8 +453,8 @@ void pt_destroy(pt_ctx* c) {
 	if(c->active.load()) { *c->abort_flag = 1; join_worker(c); }
 	(void)hipSetDevice(c->device);
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
-	for(DevBuf* b : { &c->geo, &c->cell_start, &c->cell_items, &c->cell_entries, &c->obj_range, &c->dirs, &c->disc, &c->samples, &c->offsets, &c->frame_dev, &c->fb, &c->accum, &c->counter, &c->stats_dev, &c->scratch }) b->release();
-	for(auto& p : c->pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+	for(DevBuf* b : { &c->geo, &c->cell_start, &c->cell_items, &c->cell_entries, &c->obj_range, &c->partial, &c->fracs, &c->dirs, &c->disc, &c->samples, &c->offsets, &c->frame_dev, &c->fb, &c->accum, &c->counter, &c->stats_dev, &c->scratch }) b->release();
+	for(auto& p : c->pending) for(hipEvent_t e : p) (void)hipEventDestroy(e);
 	for(hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
 	if(c->abort_flag) (void)hipHostFree(c->abort_flag);
 	if(c->counter_host) (void)hipHostFree(c->counter_host);
@@ -660,6 +683,17 @@ int pt_debug_coop_stats(pt_ctx* c, unsigned long long* out16) {
 	PT_HIP(c, hipSetDevice(c->device));
 	PT_HIP(c, hipDeviceSynchronize());
 	return ptl::coop_stats(out16);
+}
+
+int pt_sample_ranges(const pt_settings* s) {
+	if(!s) return PT_ERR_ARG;
+	const int asked = s->sample_ranges;
+	if(asked < 0 || asked > 16 || (asked & (asked - 1)) != 0) return PT_ERR_ARG;
+	if(s->frame_index >= 0) return 1;
+	if(asked > 0) return asked;
+	int ranges = 1;
+	while(ranges < 8 && ranges * 2 * 32 <= s->spp_wanted) ranges *= 2;
+	return ranges;
 }
 
 int pt_partition_tiles(int width, int height, int part_index, int part_count) {

@@ -147,12 +147,25 @@ PT_DEV float hit_sphere(V3 lp, V3 ld, V3 sp, float sr, V3& pos, V3& nrm) {
 PT_DEV bool touches_sphere(V3 lp, V3 ld, V3 sp, float sr) {  // lineSphereCollision, code/rt_math.cpp:2361-2373
 	lp = lp - sp;
 	float d = dot(ld, lp);
-	float l = length(lp);
-	float b = d * d - l * l + sr * sr;
-	if(b < 0) return false;
-	float distance = -(dot(ld, lp)) + sqrtf(b);
-	if(distance < 0) return false;
-	return true;
+	float ll = dot(lp, lp);
+	// The reference takes two square roots: b = d*d - length(lp)^2 + sr*sr must not be negative, and
+	// -d + sqrt(b) must not be negative, which is the case exactly when d <= 0 or sr*sr >= length(lp)^2.
+	// Both decisions are clear-cut for almost every ray: when the quantities are further from zero
+	// than a margin far above their rounding errors, the answer is known without the roots.
+	float rr = sr * sr;
+	float margin = 1e-5f * (d * d + ll + rr);
+	float b_est = d * d - ll + rr;
+	const bool clear_miss = b_est < -margin || (d > 0 && ll - rr > margin);
+	const bool clear_hit = b_est > margin && (d < 0 || rr - ll > margin);
+	bool touches = clear_hit;
+	if(__ballot(!clear_miss && !clear_hit) != 0) {            // wave-uniform: the roots are skipped only if no lane needs them
+		float l = sqrtf(ll);                                  // length(lp): the same sum of squares
+		float b = d * d - l * l + sr * sr;
+		bool exact = false;
+		if(b >= 0) exact = !(-(dot(ld, lp)) + sqrtf(b) < 0);
+		if(!clear_miss && !clear_hit) touches = exact;
+	}
+	return touches;
 }
 
 PT_DEV float hit_box(V3 lp, V3 ld, V3 bpos, V3 bdim, V3& pos, V3& nrm) {

@@ -7,8 +7,11 @@
 // lanes that need them.  A lane whose path ends regenerates the next sample of its pixel in the
 // same trip, and a lane whose pixel is finished pulls a new pixel from the wave's tile pool, so the
 // live rays stay compacted in the 64 lanes between bounces without ever going through memory.
-// Per-pixel sums are kept in registers in sample order, so the image is a pure function of the
-// inputs: independent of wave scheduling, grid size and GPU count.
+// The unit of work a lane takes is one RANGE of a pixel's samples (a pixel's samples are cut into
+// 2^ranges_log2 contiguous ranges): a lane sums its range in sample order in registers and stores
+// the sum; pt_k_resolve then folds a pixel's range sums in range order.  The order of every addition
+// is fixed by the inputs, so the image is a pure function of them (independent of wave scheduling,
+// grid size and GPU count), while the work units are short enough for the frame to end evenly.
 #include <cstdlib>
 
 #include "pt_device.h"
@@ -19,6 +22,7 @@ namespace {
 
 constexpr int kBlock = 256;            // 4 wavefronts; waves never synchronise with each other
 constexpr int kGroup = 64;             // pixels per pool refill = one 8x8 image tile
+constexpr uint32_t kAbortPoll = 64;    // group fetches per look at the abort word (power of two)
 #ifndef PT_TRACE_WAVES_PER_SIMD
 #define PT_TRACE_WAVES_PER_SIMD 4     // register budget of the trace kernel: 128 VGPRs
 #endif
@@ -26,6 +30,13 @@ constexpr int kGroup = 64;             // pixels per pool refill = one 8x8 image
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ int lanes_below(uint64_t mask) {
 	return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Pixel centre on the image plane (code/raycast.cpp:1050-1057).  The two quotients x/width and
+// y/height come from tables the host filled with the same divisions.
+__device__ __forceinline__ V3 pixel_origin_tab(const ptl::TraceJob& job, FrameRef fr, int x, int y) {
+	const float fx = job.col_frac[x], fy = job.row_frac[y];
+	return (ld3(fr->top_left) + ld3(fr->right_width) * fx) + ld3(fr->down_height) * fy;
 }
 
 // Lane states of the trace loop.
@@ -51,14 +62,19 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 
 	// wave-uniform tile pool: one 8x8 image tile at a time, with what all its pixels share
 	int pool_pos = kGroup;                   // next pixel of the tile to hand out; kGroup: tile used up
-	int tile_x0 = 0, tile_y0 = 0, tile_slot0 = 0, tile_mx = 0, tile_my = 0;
+	int tile_x0 = 0, tile_y0 = 0, tile_slot0 = 0, tile_mx = 0, tile_my = 0, tile_range = 0;
+	const int ranges_log2 = job.ranges_log2;
+	// the blue-noise bucket offsets (at most 17 words) are read at every hand-out: keep them in LDS
+	__shared__ int bucket[20];
+	if((int)threadIdx.x <= tile_w * tile_w) bucket[threadIdx.x] = sc.offsets[threadIdx.x];
+	__syncthreads();
 	const int mod_magic = 65536 / tile_w + 1;   // v % tile_w for v < 16 and tile_w <= 4 without a division
 	bool dry = false;
 
 	// per-lane pixel state
 	int state = NEED_PIXEL;
-	int px = 0, py = 0, si = 0, si_end = 0, n_samples = 0, sample_base = 0, lens = 0;
-	size_t out_index = 0;
+	int px = 0, py = 0, si = 0, si_end = 0, sample_base = 0, lens = 0;
+	size_t item = 0;                         // where the range sum goes: pixel slot * ranges + range
 	uint64_t pass = 0;
 	V3 origin = v3(0, 0, 0), sum = v3(0, 0, 0);
 	// per-lane path state
@@ -75,6 +91,9 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 #endif
 	PT_TICK(t_kernel);
 	PT_TICK(t_loop);
+#ifdef PT_COOP_TIMING
+	const unsigned long long wall_start = wall_clock64();    // 100 MHz, one time base for the whole chip
+#endif
 
 	for(;;) {
 		// ---- stage 0: lanes without a pixel draw one from the wave's pool -------------------
@@ -84,18 +103,25 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 		while(want != 0) {
 			if(pool_pos == kGroup) {
 				if(dry) break;
-				uint32_t g = 0, stop = 0;
+				// One wave in kAbortPoll group fetches looks at the host's abort word (a read over the bus that
+				// costs microseconds and does not scale to one per fetch); the wave that finds it set pushes the
+				// group counter past the end, which stops every other wave at its next fetch.
+				uint32_t g = 0;
 				if(lane == 0) {
-					stop = *job.abort_flag;
 					g = atomicAdd(job.group_counter, 1u);
+					if((g & (kAbortPoll - 1u)) == 0u && g < (uint32_t)job.n_groups && *job.abort_flag != 0u) {
+						atomicOr(job.group_counter, 0x80000000u);
+						g = 0x80000000u;
+					}
 				}
 				g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
-				stop = (uint32_t)__builtin_amdgcn_readfirstlane((int)stop);
-				if(stop != 0 || g >= (uint32_t)job.n_groups) { dry = true; break; }
-				const int tile = (int)g * job.part_count + job.part_index;
+				if(g >= (uint32_t)job.n_groups) { dry = true; break; }
+				const int local_tile = (int)(g >> ranges_log2);
+				const int tile = local_tile * job.part_count + job.part_index;
+				tile_range = (int)(g & ((1u << ranges_log2) - 1u));
 				tile_x0 = (tile % job.tiles_x) * 8;
 				tile_y0 = (tile / job.tiles_x) * 8;
-				tile_slot0 = (int)g * kGroup;
+				tile_slot0 = local_tile * kGroup;
 				tile_mx = tile_x0 % tile_w;
 				tile_my = tile_y0 % tile_w;
 				pool_pos = 0;
@@ -107,21 +133,26 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 				px = tile_x0 + (j & 7);
 				py = tile_y0 + (j >> 3);
 				if(px < width && py < height) {
-					out_index = job.compact ? (size_t)(tile_slot0 + j) : (size_t)py * (size_t)width + (size_t)px;
+					const size_t slot = job.compact ? (size_t)(tile_slot0 + j) : (size_t)py * (size_t)width + (size_t)px;
+					item = (slot << ranges_log2) + (size_t)tile_range;
 					const int vx = tile_mx + (j & 7), vy = tile_my + (j >> 3);
 					const int rx = vx - ((vx * mod_magic) >> 16) * tile_w, ry = vy - ((vy * mod_magic) >> 16) * tile_w;
-					int t = ry * tile_w + rx;                      // (py % tile_w) * tile_w + (px % tile_w)
-					sample_base = sc.offsets[t];
-					n_samples = sc.offsets[t + 1] - sample_base;
-					if(n_samples == 0) {
-						// a blue-noise tile without samples: the reference divides 0/0 here (code/raycast.cpp:1270)
-						float* o = job.fb + out_index * 3;
-						o[0] = 0; o[1] = 0; o[2] = 0;
+					const int t = ry * tile_w + rx;                // (py % tile_w) * tile_w + (px % tile_w)
+					sample_base = bucket[t];
+					const int n_samples = bucket[t + 1] - sample_base;
+					if(job.frame_index < 0) {
+						si = (tile_range * n_samples) >> ranges_log2;
+						si_end = ((tile_range + 1) * n_samples) >> ranges_log2;
+						pass = 0;
+					} else if(n_samples > 0) {
+						si = job.frame_index % n_samples; si_end = si + 1; pass = (uint64_t)(job.frame_index / n_samples);
+					} else { si = 0; si_end = 0; }
+					if(si == si_end) {
+						// nothing to trace (a bucket without samples, code/raycast.cpp:1270, or fewer samples than ranges)
+						job.partial[item] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(job.serial));
 					} else {
-						if(job.frame_index < 0) { si = 0; si_end = n_samples; pass = 0; }
-						else { si = job.frame_index % n_samples; si_end = si + 1; pass = (uint64_t)(job.frame_index / n_samples); }
 						lens = fr->aperture != 0.0f ? lens_start(fr, px, py) : 0;
-						if(MODE != CAST_GRID_COOP) origin = pixel_origin(fr, px, py);
+						if(MODE != CAST_GRID_COOP) origin = pixel_origin_tab(job, fr, px, py);
 						sum = v3(0, 0, 0);
 						state = NEED_PATH;
 					}
@@ -140,8 +171,8 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 		if(state == NEED_PATH) {
 			v2f s = sc.samples[sample_base + si];
 			// the cooperative cast is short of registers: it recomputes what the other variants keep per pixel
-			const V3 from = MODE == CAST_GRID_COOP ? pixel_origin(fr, px, py) : origin;
-			const uint64_t round = MODE == CAST_GRID_COOP ? (job.frame_index < 0 ? 0ull : (uint64_t)(job.frame_index / n_samples)) : pass;
+			const V3 from = MODE == CAST_GRID_COOP ? pixel_origin_tab(job, fr, px, py) : origin;
+			const uint64_t round = pass;
 			camera_ray(sc, fr, from, s, lens + si, rp, rd);
 			sample_stream(fr, px, py, si, round, rng);
 			att = v3(1, 1, 1);
@@ -180,18 +211,7 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 				si++;
 				state = NEED_PATH;
 				if(si == si_end) {
-					float* o = job.fb + out_index * 3;
-					if(job.frame_index < 0) {
-						V3 c = clamp_hi(sum / (float)n_samples, 1.0f);   // code/raycast.cpp:1270
-						o[0] = c.x; o[1] = c.y; o[2] = c.z;
-					} else {
-						float* a = job.accum + out_index * 3;
-						V3 t = sum;
-						if(job.frame_index > 0) t = v3(a[0] + sum.x, a[1] + sum.y, a[2] + sum.z);
-						a[0] = t.x; a[1] = t.y; a[2] = t.z;
-						V3 c = clamp_hi(t / (float)(job.frame_index + 1), 1.0f);
-						o[0] = c.x; o[1] = c.y; o[2] = c.z;
-					}
+					job.partial[item] = make_float4(sum.x, sum.y, sum.z, __uint_as_float(job.serial));
 					state = NEED_PIXEL;
 				}
 			}
@@ -202,13 +222,68 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 	PT_TOCK(coop, MODE == CAST_GRID_COOP ? 15 : 12, t_loop);
 	PT_TOCK(coop, 0, t_kernel);
 #ifdef PT_COOP_TIMING
-	if(lane == 0) for(int i = 0; i < 16; i++) PT_COUNT_(i, coop.tacc[i]);
+	if(lane == 0) {
+		for(int i = 0; i < 16; i++) PT_COUNT_(i, coop.tacc[i]);
+		if(MODE != CAST_GRID_COOP) {      // how evenly the wavefronts finish: busy time per wave against the kernel's span
+			const unsigned long long wall_end = wall_clock64();
+			PT_COUNT_(2, wall_end - wall_start);
+			PT_COUNT_(5, 1);
+			atomicMin(&g_coop_stats[3], wall_start);
+			atomicMax(&g_coop_stats[4], wall_end);
+		}
+	}
 #endif
 	// ray-cast count: one atomic per wave
 	if(job.stats) {
 		uint32_t total = casts;
 		for(int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
 		if(lane == 0) atomicAdd((unsigned long long*)job.stats, (unsigned long long)total);
+	}
+}
+
+// Folds the range sums of every pixel, in range order, into the image (code/raycast.cpp:1263-1270:
+// average of the per-sample clamped colours, clamped again).  A pixel whose ranges do not all carry
+// this launch's serial number was not finished (aborted render) and keeps its previous content.
+__global__ __launch_bounds__(kBlock) void pt_k_resolve(ptl::TraceJob job, size_t slots) {
+	const size_t slot = (size_t)blockIdx.x * kBlock + threadIdx.x;
+	if(slot >= slots) return;
+	const Scene sc = scene_view(job.scene);
+	const FrameRef fr = (FrameRef)job.frame;
+	int px, py;
+	if(job.compact) {
+		const int tile = (int)(slot / kGroup) * job.part_count + job.part_index, j = (int)(slot % kGroup);
+		px = (tile % job.tiles_x) * 8 + (j & 7);
+		py = (tile / job.tiles_x) * 8 + (j >> 3);
+		if(px >= fr->width || py >= fr->height) return;
+	} else {
+		px = (int)(slot % (size_t)fr->width);
+		py = (int)(slot / (size_t)fr->width);
+	}
+	const int t = (py % fr->tile_w) * fr->tile_w + (px % fr->tile_w);
+	const int n_samples = sc.offsets[t + 1] - sc.offsets[t];
+	const int ranges = 1 << job.ranges_log2;
+	const float4* part = job.partial + (slot << job.ranges_log2);
+	float4 first = part[0];
+	bool whole = __float_as_uint(first.w) == job.serial;
+	V3 sum = v3(first.x, first.y, first.z);
+	for(int r = 1; r < ranges; r++) {
+		float4 next = part[r];
+		whole = whole && __float_as_uint(next.w) == job.serial;
+		sum = sum + v3(next.x, next.y, next.z);
+	}
+	if(!whole) return;
+	float* o = job.fb + slot * 3;
+	if(n_samples == 0) { o[0] = 0; o[1] = 0; o[2] = 0; return; }
+	if(job.frame_index < 0) {
+		V3 c = clamp_hi(sum / (float)n_samples, 1.0f);
+		o[0] = c.x; o[1] = c.y; o[2] = c.z;
+	} else {
+		float* a = job.accum + slot * 3;
+		V3 total = sum;
+		if(job.frame_index > 0) total = v3(a[0] + sum.x, a[1] + sum.y, a[2] + sum.z);
+		a[0] = total.x; a[1] = total.y; a[2] = total.z;
+		V3 c = clamp_hi(total / (float)(job.frame_index + 1), 1.0f);
+		o[0] = c.x; o[1] = c.y; o[2] = c.z;
 	}
 }
 
@@ -289,6 +364,7 @@ const char* trace_kernel_name() { return "pt_k_trace"; }
 int coop_stats(unsigned long long* out16) {
 #if defined(PT_COOP_STATS) || defined(PT_COOP_TIMING)
 	unsigned long long zero[16] = { 0 };
+	zero[3] = ~0ull;      // slot 3 is a minimum
 	if(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_coop_stats), sizeof zero) != hipSuccess) return -1;
 	if(hipMemcpyToSymbol(HIP_SYMBOL(g_coop_stats), zero, sizeof zero) != hipSuccess) return -1;
 	return 16;
@@ -319,7 +395,7 @@ hipError_t launch_trace(const TraceJob& job, hipStream_t stream, int* grid_block
 	}
 	hipError_t e = hipMemsetAsync(job.group_counter, 0, sizeof(uint32_t), stream);
 	if(e != hipSuccess) return e;
-	// persistent launch: every resident wave pulls 64-pixel tiles until the partition is drained
+	// persistent launch: every resident wave pulls groups of 64 work items until the partition is drained
 	long blocks = ((long)job.n_groups + 3) / 4;
 	long resident = (long)cus * blocks_per_cu[mode];
 	if(blocks > resident) blocks = resident;
@@ -328,6 +404,12 @@ hipError_t launch_trace(const TraceJob& job, hipStream_t stream, int* grid_block
 	if(mode == CAST_BRUTE) hipLaunchKernelGGL(pt_k_trace<CAST_BRUTE>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
 	else if(mode == CAST_GRID_LANE) hipLaunchKernelGGL(pt_k_trace<CAST_GRID_LANE>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
 	else hipLaunchKernelGGL(pt_k_trace<CAST_GRID_COOP>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
+	return hipGetLastError();
+}
+
+hipError_t launch_resolve(const TraceJob& job, size_t slots, hipStream_t stream) {
+	if(slots == 0) return hipSuccess;
+	hipLaunchKernelGGL(pt_k_resolve, dim3((unsigned)((slots + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, job, slots);
 	return hipGetLastError();
 }
 

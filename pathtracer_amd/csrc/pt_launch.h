@@ -36,24 +36,30 @@ struct FrameDev {
 	uint64_t seed;
 };
 
-// Pixels are handed to wavefronts in groups of 64 = one 8x8 image tile.  A context renders the
-// tiles t with t % part_count == part_index.
+// Work is handed to wavefronts in groups of 64 items = one 8x8 image tile x one range of each
+// pixel's samples.  A context renders the tiles t with t % part_count == part_index.
 struct TraceJob {
 	SceneDev scene;
 	const FrameDev* frame;      // device copy of the per-frame constants
+	float4* partial;            // [pixel slot][range]: sum of the range's clamped sample colours | launch serial
+	const float* col_frac;      // x / width for every column, y / height for every row
+	const float* row_frac;
+	uint32_t serial;            // marks the range sums of this launch
+	int ranges_log2;            // a pixel's samples are summed in 2^ranges_log2 contiguous ranges
 	float* fb;                  // row-major image, or tile-major [local tile][64][3] when compact
 	float* accum;               // progressive accumulation buffer (same layout as fb), may be null
 	uint32_t* group_counter;    // device word, zeroed by the launcher
 	const volatile uint32_t* abort_flag;   // host-pinned word, non-zero = stop fetching tiles
 	uint64_t* stats;            // device: [0] ray casts
 	int tiles_x, tiles_y;
-	int n_groups;               // tiles owned by this partition
+	int n_groups;               // tiles owned by this partition x ranges
 	int part_index, part_count;
 	int frame_index;            // -1: every sample; >= 0: one sample, progressive
 	int compact;
 };
 
 hipError_t launch_trace(const TraceJob& job, hipStream_t stream, int* grid_blocks_out);
+hipError_t launch_resolve(const TraceJob& job, size_t slots, hipStream_t stream);
 hipError_t launch_primary_aov(const SceneDev& sc, const FrameDev* fr, int width, int height, int32_t* hit_id, uint64_t* cell_hash, hipStream_t stream);
 hipError_t launch_cast(const SceneDev& sc, const float* origins, const float* dirs, int n, int32_t* hit_id,
                        float* hit_pos, float* hit_nrm, hipStream_t stream);

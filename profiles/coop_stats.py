@@ -23,6 +23,9 @@ casts = s.rays
 print(name, "casts", casts, "kernel_ms %.2f" % s.trace_ms)
 names += ["cyc_walk|handout", "cyc_expand|camera", "cyc_drain|shade", "cyc_verdict", "cyc_cast", "cyc_generate_shade"]
 print("  wave cycles total %d" % buf[0])
+if buf[5]:
+    span = (buf[4] - buf[3]) / 100.0
+    print("  waves %d  kernel span %.1f us  mean wave busy %.1f us  = %.1f %% of the span" % (buf[5], span, buf[2] / buf[5] / 100.0, buf[2] / buf[5] / (buf[4] - buf[3]) * 100))
 tn = {2: "chunk_fetch", 3: "chunk_intersect", 4: "chunk_cellsearch", 5: "chunk_writeback"}
 for i in range(2, 6):
     print(f"  {tn[i]:20s} {buf[i]:14d}  {100.0 * buf[i] / max(1, buf[0]):5.1f} % of wave time   per segment {buf[i] / max(1, buf[1]):8.0f}")
