@@ -200,7 +200,7 @@ def main():
 
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     p = torch.tensor([float(stats.paths)], dtype=torch.float64, device="cuda")
-    k = torch.tensor([float(kstats.trace_ms)], dtype=torch.float64, device="cuda")
+    k = torch.tensor([float(kstats.dominant_kernel_ms)], dtype=torch.float64, device="cuda")
     if world_size > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(p, op=dist.ReduceOp.SUM)

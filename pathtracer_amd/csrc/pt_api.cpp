@@ -230,7 +230,7 @@ int prepare(pt_ctx* c) {
 	c->fb_floats = compact ? (size_t)c->local_tiles * 64 * 3 : (size_t)s.width * s.height * 3;
 	PT_HIP(c, c->fb.reserve(c->fb_floats * 4));
 	if(s.frame_index >= 0) PT_HIP(c, c->accum.reserve(c->fb_floats * 4));
-	PT_HIP(c, c->counter.reserve(256));
+	PT_HIP(c, c->counter.reserve(8192));      // the launcher's group counters, one cache line each
 	PT_HIP(c, c->stats_dev.reserve(256));
 	// range sums of every pixel slot, and the quotients x/width, y/height (the divisions of code/raycast.cpp:1050)
 	const int sum_ranges = pt_sample_ranges(&s);

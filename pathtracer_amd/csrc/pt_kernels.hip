@@ -23,6 +23,11 @@ namespace {
 constexpr int kBlock = 256;            // 4 wavefronts; waves never synchronise with each other
 constexpr int kGroup = 64;             // pixels per pool refill = one 8x8 image tile
 constexpr uint32_t kAbortPoll = 64;    // group fetches per look at the abort word (power of two)
+#ifndef PT_COUNTER_SHARDS
+#define PT_COUNTER_SHARDS 8
+#endif
+constexpr uint32_t kShards = PT_COUNTER_SHARDS;      // group counters
+constexpr uint32_t kShardStride = 32;  // words between them (128 bytes)
 #ifndef PT_TRACE_WAVES_PER_SIMD
 #define PT_TRACE_WAVES_PER_SIMD 4     // register budget of the trace kernel: 128 VGPRs
 #endif
@@ -70,6 +75,7 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 	__syncthreads();
 	const int mod_magic = 65536 / tile_w + 1;   // v % tile_w for v < 16 and tile_w <= 4 without a division
 	bool dry = false;
+	uint32_t shard = blockIdx.x % kShards;     // lane 0's view is the one that counts
 
 	// per-lane pixel state
 	int state = NEED_PIXEL;
@@ -103,14 +109,22 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 		while(want != 0) {
 			if(pool_pos == kGroup) {
 				if(dry) break;
-				// One wave in kAbortPoll group fetches looks at the host's abort word (a read over the bus that
-				// costs microseconds and does not scale to one per fetch); the wave that finds it set pushes the
-				// group counter past the end, which stops every other wave at its next fetch.
-				uint32_t g = 0;
+				// Groups are dealt from kShards counters (group = count * kShards + shard), each on a cache
+				// line of its own, so that fetches do not queue up behind one address; a wave starts at the
+				// shard of its block (blocks go round the XCDs, so mostly that XCD's L2 serves it) and moves on
+				// when a shard runs out.  One wave in kAbortPoll fetches looks at the host's abort word (a read
+				// over the bus that costs microseconds and does not scale to one per fetch); the wave that finds
+				// it set pushes every counter past the end, which stops all other waves at their next fetch.
+				uint32_t g = 0x80000000u;
 				if(lane == 0) {
-					g = atomicAdd(job.group_counter, 1u);
-					if((g & (kAbortPoll - 1u)) == 0u && g < (uint32_t)job.n_groups && *job.abort_flag != 0u) {
-						atomicOr(job.group_counter, 0x80000000u);
+					for(uint32_t tried = 0; tried < kShards; tried++) {
+						const uint32_t count = atomicAdd(job.group_counter + shard * kShardStride, 1u);
+						const uint32_t cand = count < 0x04000000u ? count * kShards + shard : 0x80000000u;
+						if(cand < (uint32_t)job.n_groups) { g = cand; break; }
+						shard = (shard + 1u) % kShards;
+					}
+					if(g != 0x80000000u && (g & (kAbortPoll - 1u)) == 0u && *job.abort_flag != 0u) {
+						for(uint32_t k = 0; k < kShards; k++) atomicOr(job.group_counter + k * kShardStride, 0x80000000u);
 						g = 0x80000000u;
 					}
 				}
@@ -393,7 +407,7 @@ hipError_t launch_trace(const TraceJob& job, hipStream_t stream, int* grid_block
 		if(e != hipSuccess) return e;
 		blocks_per_cu[mode] = b > 0 ? b : 1;
 	}
-	hipError_t e = hipMemsetAsync(job.group_counter, 0, sizeof(uint32_t), stream);
+	hipError_t e = hipMemsetAsync(job.group_counter, 0, (size_t)kShards * kShardStride * sizeof(uint32_t), stream);
 	if(e != hipSuccess) return e;
 	// persistent launch: every resident wave pulls groups of 64 work items until the partition is drained
 	long blocks = ((long)job.n_groups + 3) / 4;

@@ -48,7 +48,7 @@ struct TraceJob {
 	int ranges_log2;            // a pixel's samples are summed in 2^ranges_log2 contiguous ranges
 	float* fb;                  // row-major image, or tile-major [local tile][64][3] when compact
 	float* accum;               // progressive accumulation buffer (same layout as fb), may be null
-	uint32_t* group_counter;    // device word, zeroed by the launcher
+	uint32_t* group_counter;    // device words (8 KB reserved), zeroed by the launcher
 	const volatile uint32_t* abort_flag;   // host-pinned word, non-zero = stop fetching tiles
 	uint64_t* stats;            // device: [0] ray casts
 	int tiles_x, tiles_y;

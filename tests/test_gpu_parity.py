@@ -117,6 +117,31 @@ def test_image_parity(gpu, name, w, h, spp, bounces):
     assert mse < 1e-9
 
 
+@pytest.mark.parametrize("name,w,h,spp,ranges", [("default", 160, 90, 64, 0), ("default", 160, 90, 64, 1), ("default", 160, 90, 64, 8),
+                                                  ("default_grid", 96, 54, 40, 16), ("glass", 96, 54, 64, 4), ("default", 64, 36, 4, 16)])
+def test_sample_range_sums(gpu, name, w, h, spp, ranges):
+    """A pixel's samples are added range by range and the range sums in range order: the device's work
+    items are those ranges (different lanes, any order in time), the oracle adds in the same order, so
+    the images agree as before; against one range (the reference's single sequence) only the rounding
+    of the sum moves.  16 ranges over buckets of a few samples leaves some ranges empty."""
+    world, objs = CASES[name][0]()
+    st = settings_for(name, w, h, spp, 8, sample_ranges=ranges)
+    img = gpu.render(world, objs, st)
+    sc = OracleScene(world, objs, st)
+    ref = sc.render(policy=3, threads=8)
+    sc.close()
+    if name in ROUGH_FREE:
+        assert (bits(img) == bits(ref)).all()
+    else:
+        e = rel_err(img, ref)
+        assert (e > REL_TOL).mean() <= EDGE_FRACTION, e.max()
+    st1 = settings_for(name, w, h, spp, 8, sample_ranges=1)
+    one = gpu.render(world, objs, st1)
+    assert np.abs(img.astype(np.float64) - one).max() <= 4e-6, "range sums may differ from one sequence by rounding only"
+    expect = api.load_core().pt_sample_ranges(C.byref(st))
+    assert expect == (ranges if ranges else 2)
+
+
 def test_per_sample_radiance_via_progressive_frames(gpu):
     """Frame f of the progressive mode traces sample (f mod count) of every pixel, so the first frames
     expose single-sample radiance: each must match the oracle within 1e-4 relative."""

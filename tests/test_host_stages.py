@@ -118,3 +118,21 @@ def test_host_stage_argument_errors(core_lib):
     assert core_lib.pt_host_tables(1, 16, 9, None, None, None, 0, None, None) != 0
     d = np.zeros(9, np.int32)
     assert core_lib.pt_host_grid(None, 0, 10, iptr(d), None, 0, None, 0, None, None) != 0
+
+
+def test_sample_ranges_rule(core_lib):
+    """pt_sample_ranges: the asked count, or from spp_wanted; always 1 for progressive frames."""
+    import ctypes as C
+    from pathtracer_amd.api import default_settings
+    got = {}
+    for spp in (1, 16, 31, 32, 64, 127, 128, 256, 4096):
+        st = default_settings(64, 36, spp, 8)
+        got[spp] = core_lib.pt_sample_ranges(C.byref(st))
+    assert got == {1: 1, 16: 1, 31: 1, 32: 1, 64: 2, 127: 2, 128: 4, 256: 8, 4096: 8}
+    st = default_settings(64, 36, 64, 8, sample_ranges=16)
+    assert core_lib.pt_sample_ranges(C.byref(st)) == 16
+    st.frame_index = 3
+    assert core_lib.pt_sample_ranges(C.byref(st)) == 1
+    for bad in (3, 32, -1):
+        st = default_settings(64, 36, 64, 8, sample_ranges=bad)
+        assert core_lib.pt_sample_ranges(C.byref(st)) < 0

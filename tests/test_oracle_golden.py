@@ -184,3 +184,20 @@ def test_zero_sample_tile_is_black_not_nan(oracle_lib):
             break
         sc.close()
     assert found
+
+
+def test_range_sums_only_move_rounding(oracle_lib):
+    """Per-sample policy: 1 range is the reference's single sequence of additions; more ranges change
+    the image by rounding only, and progressive accumulation (one sample per frame) is unaffected."""
+    from oracle.oraclebind import OracleScene
+    from pathtracer_amd import scenes
+    from pathtracer_amd.api import default_settings
+    world, objs = scenes.default_scene()
+    imgs = {}
+    for ranges in (1, 2, 8):
+        sc = OracleScene(world, objs, default_settings(48, 27, 64, 8, seed=99, sample_ranges=ranges))
+        imgs[ranges] = sc.render(policy=3, threads=4)
+        sc.close()
+    assert np.abs(imgs[2].astype(np.float64) - imgs[1]).max() <= 4e-6
+    assert np.abs(imgs[8].astype(np.float64) - imgs[1]).max() <= 4e-6
+    assert (imgs[2] != imgs[1]).any() or (imgs[8] != imgs[1]).any()
