@@ -288,6 +288,7 @@ int prepare(pt_ctx* c) {
 	j.col_frac = c->fracs.as<float>();
 	j.row_frac = c->fracs.as<float>() + s.width;
 	j.ranges_log2 = ranges_log2;
+	j.slots = c->fb_floats / 3;
 	j.fb = c->fb.as<float>();
 	j.accum = s.frame_index >= 0 ? c->accum.as<float>() : nullptr;
 	j.group_counter = c->counter.as<uint32_t>();

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 	// per-lane pixel state
 	int state = NEED_PIXEL;
 	int px = 0, py = 0, si = 0, si_end = 0, sample_base = 0, lens = 0;
-	size_t item = 0;                         // where the range sum goes: pixel slot * ranges + range
+	size_t item = 0;                         // where the range sum goes: range * pixel slots + pixel slot
 	uint64_t pass = 0;
 	V3 origin = v3(0, 0, 0), sum = v3(0, 0, 0);
 	// per-lane path state
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 				py = tile_y0 + (j >> 3);
 				if(px < width && py < height) {
 					const size_t slot = job.compact ? (size_t)(tile_slot0 + j) : (size_t)py * (size_t)width + (size_t)px;
-					item = (slot << ranges_log2) + (size_t)tile_range;
+					item = (size_t)tile_range * job.slots + slot;         // range-major: the 8 pixels of a tile row fill one 128-byte line
 					const int vx = tile_mx + (j & 7), vy = tile_my + (j >> 3);
 					const int rx = vx - ((vx * mod_magic) >> 16) * tile_w, ry = vy - ((vy * mod_magic) >> 16) * tile_w;
 					const int t = ry * tile_w + rx;                // (py % tile_w) * tile_w + (px % tile_w)
@@ -276,12 +276,12 @@ __global__ __launch_bounds__(kBlock) void pt_k_resolve(ptl::TraceJob job, size_t
 	const int t = (py % fr->tile_w) * fr->tile_w + (px % fr->tile_w);
 	const int n_samples = sc.offsets[t + 1] - sc.offsets[t];
 	const int ranges = 1 << job.ranges_log2;
-	const float4* part = job.partial + (slot << job.ranges_log2);
+	const float4* part = job.partial + slot;
 	float4 first = part[0];
 	bool whole = __float_as_uint(first.w) == job.serial;
 	V3 sum = v3(first.x, first.y, first.z);
 	for(int r = 1; r < ranges; r++) {
-		float4 next = part[r];
+		float4 next = part[(size_t)r * slots];
 		whole = whole && __float_as_uint(next.w) == job.serial;
 		sum = sum + v3(next.x, next.y, next.z);
 	}

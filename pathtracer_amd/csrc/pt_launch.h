@@ -41,7 +41,8 @@ struct FrameDev {
 struct TraceJob {
 	SceneDev scene;
 	const FrameDev* frame;      // device copy of the per-frame constants
-	float4* partial;            // [pixel slot][range]: sum of the range's clamped sample colours | launch serial
+	float4* partial;            // [range][pixel slot]: sum of the range's clamped sample colours | launch serial
+	size_t slots;               // pixel slots of the framebuffer (pixels, or 64 per owned tile when compact)
 	const float* col_frac;      // x / width for every column, y / height for every row
 	const float* row_frac;
 	uint32_t serial;            // marks the range sums of this launch
