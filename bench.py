@@ -45,7 +45,12 @@ FLOP_WEIGHTS = {
     "paths": 25 + 6,        # camera ray + accumulate
     "lens": 40,
 }
-PEAK_FP32_VALU_TFLOPS = 157.3      # MI355X vector fp32 peak (packed FMA); plain add/mul code can reach half of it
+PEAK_FP32_VALU_TFLOPS = 157.3      # MI355X vector fp32 peak: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz x 2 (FMA) x 2 (packed)
+PEAK_SCALAR_ISSUE_TFLOPS = 39.3    # the same lanes issuing one plain add/mul per lane and cycle: what code that must
+                                   # round every operation like the reference (no FMA contraction, no packing) can reach
+# flop/path of the named workloads as counted by the CPU leg (oracle event counters x FLOP_WEIGHTS); used
+# when the CPU leg is skipped (--no-cpu, more than one GPU) so that the roofline block is always filled
+KNOWN_FLOPS_PER_PATH = {"demo-1080p-64spp-d8": 259.5531495662587}
 
 
 def flops_from_counters(c):
@@ -231,8 +236,12 @@ def main():
             flops_per_launch = flops_per_path * total_paths / world_size
             roof["flops_per_path"] = flops_per_path
             roof["achieved"] = flops_per_launch / (kernel_ms * 1e-3) / 1e12
+        elif args.workload in KNOWN_FLOPS_PER_PATH:
+            roof["flops_per_path"] = KNOWN_FLOPS_PER_PATH[args.workload]
+            roof["achieved"] = roof["flops_per_path"] * total_paths / world_size / (kernel_ms * 1e-3) / 1e12
+        if roof["achieved"] is not None:
             roof["frac"] = roof["achieved"] / PEAK_FP32_VALU_TFLOPS
-            roof["frac_of_no_fma_peak"] = roof["achieved"] / (PEAK_FP32_VALU_TFLOPS / 2)
+            roof["frac_of_scalar_issue_peak"] = roof["achieved"] / PEAK_SCALAR_ISSUE_TFLOPS
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
@@ -243,8 +252,9 @@ def main():
             except Exception:
                 pass
         out["roofline"] = roof
-        # algorithmic HBM bytes of the frame: the fp32 framebuffer (12 B per pixel), written once
-        out["hbm_algorithmic_bytes_per_launch"] = int(12 * stats.pixels)
+        # algorithmic HBM bytes of the trace kernel: one 16-byte range sum per pixel and range, written once
+        # (pt_k_resolve then reads them and writes the 12-byte pixels)
+        out["hbm_algorithmic_bytes_per_launch"] = int(16 * stats.pixels * api.load_core().pt_sample_ranges(C.byref(st)))
         print(json.dumps(out), flush=True)
     r.close()
     if world_size > 1:
