@@ -186,6 +186,14 @@ int pt_get_stats(const pt_ctx* ctx, pt_stats* stats);
  * the prepared scene.
  */
 int pt_debug_primary(pt_ctx* ctx, int32_t* hit_id, uint64_t* cell_hash);
+/* Debug read-back of the uniform grid the prepared scene uses (the reference's per-cell ObjectLists,
+ * code/app.cpp:1278-1354, in CSR form; built on the device for scenes of 4096 entities or more, on
+ * the host otherwise; the environment variable PT_GRID_BUILD=host|device overrides the choice).
+ * cell_start: cells + 1 words; cell_items: the lists, ascending entity id per cell; obj_range: two
+ * words per entity (inclusive cell range, 10 bits per axis, kind in the top bits).  Any pointer may
+ * be NULL; the totals are always reported. */
+int pt_debug_grid(pt_ctx* ctx, uint32_t* cell_start, int cell_capacity, uint32_t* cell_items, int item_capacity,
+                  uint32_t* obj_range, int* cell_total, int* item_total, int* built_on_device);
 
 /* One-ray query through the prepared scene: the editor's picking ray (code/app.cpp:1634-1637)
  * and focal-distance picker (code/app.cpp:3233-3247). Returns the 1-based id or 0. */

@@ -169,6 +169,9 @@ def load_core():
                                  C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32), C.c_int,
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.pt_sync.argtypes = [C.c_void_p]
+    lib.pt_debug_grid.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32),
+                                  C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.pt_sample_ranges.argtypes = [C.POINTER(pt_settings)]
     lib.pt_partition_tiles.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.pt_scene_load.argtypes = [C.c_char_p, C.POINTER(pt_world), C.POINTER(pt_object), C.c_int, C.POINTER(C.c_int)]
     lib.pt_scene_save.argtypes = [C.c_char_p, C.POINTER(pt_world), C.POINTER(pt_object), C.c_int]
@@ -244,6 +247,17 @@ class Renderer:
 
     def sync(self):
         self._check(self.lib.pt_sync(self.ctx), "pt_sync")
+
+    def debug_grid(self):
+        """(cell_start, cell_items, obj_range, built_on_device) of the prepared scene's grid."""
+        cells, items, dev = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._check(self.lib.pt_debug_grid(self.ctx, None, 0, None, 0, None, C.byref(cells), C.byref(items), C.byref(dev)), "pt_debug_grid")
+        start = np.zeros(cells.value + 1, np.uint32)
+        lists = np.zeros(max(1, items.value), np.uint32)
+        ranges = np.zeros(max(1, 2 * self.stats().objects), np.uint32)
+        self._check(self.lib.pt_debug_grid(self.ctx, uptr(start), start.size, uptr(lists), lists.size, uptr(ranges),
+                                           C.byref(cells), C.byref(items), C.byref(dev)), "pt_debug_grid")
+        return start, lists[:items.value], ranges[:2 * self.stats().objects], bool(dev.value)
 
     def set_frame(self, frame):
         self._check(self.lib.pt_set_frame(self.ctx, frame), "pt_set_frame")

@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -55,12 +56,13 @@ struct pt_ctx {
 	bool prepared = false;
 
 	// device-resident scene
-	DevBuf geo, cell_start, cell_items, cell_entries, obj_range, partial, fracs, dirs, disc, samples, offsets, frame_dev, fb, accum, counter, stats_dev, scratch;
+	DevBuf geo, cell_start, cell_items, cell_entries, obj_range, partial, fracs, bbox, grid_cursor, grid_sums, dirs, disc, samples, offsets, frame_dev, fb, accum, counter, stats_dev, scratch;
 	uint32_t* abort_flag = nullptr;      // host-pinned, read by the trace kernel
 	uint32_t* abort_flag_dev = nullptr;  // the same word as the device addresses it
 	uint32_t* counter_host = nullptr;    // host-pinned landing word for progress polls
 	ptl::TraceJob job{};
 	size_t fb_floats = 0;
+	bool grid_built_on_device = false;
 	uint32_t serial = 0;        // launch counter: marks the range sums each launch writes
 	int local_tiles = 0;
 
@@ -125,6 +127,47 @@ int upload(pt_ctx* c, DevBuf& b, const void* src, size_t bytes) {
 }
 
 // pt_prepare body; the caller holds no lock and has set the device.
+// Per-cell lists, entity cell ranges and the cooperative cast's list entries built on the device
+// (pt_gridbuild.hip) from the uploaded entity records.  *done is false when a cell lists more than
+// kLongestDeviceList entities: the ordering pass sorts a list with one thread, so the host builds then.
+constexpr uint32_t kLongestDeviceList = 4096;
+int grid_build_device(pt_ctx* c, const std::vector<float>& rec, int n, const pt::GridDesc& gd, size_t* item_total, bool* done) {
+	*done = false;
+	const size_t cells = (size_t)gd.cells();
+	std::vector<float> box((size_t)n * 4, 0.0f);
+	for(int i = 0; i < n; i++) memcpy(box.data() + (size_t)i * 4, rec.data() + (size_t)i * PT_F_STRIDE + PT_F_BBOX, 12);
+	int rc;
+	if((rc = upload(c, c->bbox, box.data(), box.size() * 4))) return rc;
+	PT_HIP(c, c->cell_start.reserve((cells + 1) * 4));
+	PT_HIP(c, c->grid_cursor.reserve(cells * 4));
+	PT_HIP(c, c->grid_sums.reserve(ptl::grid_scan_blocks(cells) * 4 + 256));
+	PT_HIP(c, c->obj_range.reserve((size_t)n * 8));
+	ptl::GridBuildJob job{};
+	job.geo = c->geo.as<float4>();
+	job.bbox = c->bbox.as<float4>();
+	job.n = n;
+	for(int k = 0; k < 3; k++) { job.grid.cmin[k] = gd.coord_min[k]; job.grid.cnt[k] = gd.cell_count[k]; job.grid.cs[k] = gd.cell_size[k]; job.grid.inv_cs[k] = 1.0f / (float)gd.cell_size[k]; }
+	job.obj_range = c->obj_range.as<uint32_t>();
+	job.cell_start = c->cell_start.as<uint32_t>();
+	job.cursor = c->grid_cursor.as<uint32_t>();
+	job.block_sums = c->grid_sums.as<uint32_t>();
+	job.longest = c->grid_sums.as<uint32_t>() + ptl::grid_scan_blocks(cells);
+	PT_HIP(c, ptl::launch_grid_count_scan(job, cells, c->stream));
+	uint32_t total = 0, longest = 0;
+	PT_HIP(c, hipMemcpyAsync(&total, job.cell_start + cells, 4, hipMemcpyDeviceToHost, c->stream));
+	PT_HIP(c, hipMemcpyAsync(&longest, job.longest, 4, hipMemcpyDeviceToHost, c->stream));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	if(longest > kLongestDeviceList) return PT_OK;
+	PT_HIP(c, c->cell_items.reserve(((size_t)total + 1) * 4));
+	PT_HIP(c, c->cell_entries.reserve(((size_t)total + 1) * 16));
+	job.cell_items = c->cell_items.as<uint32_t>();
+	job.cell_entries = c->cell_entries.as<float4>();
+	PT_HIP(c, ptl::launch_grid_fill(job, cells, c->stream));
+	*item_total = total;
+	*done = true;
+	return PT_OK;
+}
+
 int prepare(pt_ctx* c) {
 	auto t0 = std::chrono::steady_clock::now();
 	const pt_settings& s = c->st;
@@ -149,13 +192,17 @@ int prepare(pt_ctx* c) {
 
 	pt::GridDesc gd{};
 	std::vector<uint32_t> cell_start, cell_items;
-	bool have_grid = pt::build_grid(rec.data(), n, s.grid_hint, &gd, &cell_start, &cell_items);
+	bool have_grid = pt::grid_desc(rec.data(), n, s.grid_hint, &gd);
 	if(!have_grid) {
 		if(n > 0) return fail(c, PT_ERR_LIMIT, "the scene's extent gives an unusable grid (non-finite bounds or more than 2^28 cells)");
 		gd = pt::GridDesc{ { 0, 0, 0 }, { 1, 1, 1 }, { 1, 1, 1 } };
 		cell_start.assign(2, 0);
-		cell_items.clear();
 	}
+	// The per-cell lists are built on the device for large scenes (PT_GRID_BUILD=host|device overrides the
+	// choice); the packed cell ranges the device passes use hold 10 bits per axis and 23 bits of entity id.
+	const bool ranges_fit = gd.cell_count[0] <= 1023 && gd.cell_count[1] <= 1023 && gd.cell_count[2] <= 1023 && n < (1 << 23);
+	const char* where = getenv("PT_GRID_BUILD");
+	bool grid_on_device = have_grid && ranges_fit && (where ? strcmp(where, "device") == 0 : n >= 4096);
 
 	// one 128-byte record of eight float4 per entity (layout documented in pt_device.h)
 	const size_t np = (size_t)(n > 0 ? n : 1);
@@ -183,12 +230,24 @@ int prepare(pt_ctx* c) {
 
 	int rc;
 	if((rc = upload(c, c->geo, geo.data(), geo.size() * 4))) return rc;
-	if((rc = upload(c, c->cell_start, cell_start.data(), cell_start.size() * 4))) return rc;
-	if((rc = upload(c, c->cell_items, cell_items.data(), cell_items.size() * 4))) return rc;
-	std::vector<uint32_t> ranges;
-	bool coop = pt::object_ranges(rec.data(), n, gd, &ranges);
-	if((rc = upload(c, c->obj_range, ranges.data(), ranges.size() * 4))) return rc;
-	{
+	bool coop = false;
+	size_t item_total = 0;
+	c->grid_built_on_device = false;
+	if(grid_on_device) {
+		bool done = false;
+		if((rc = grid_build_device(c, rec, n, gd, &item_total, &done))) return rc;
+		grid_on_device = done;           // a very long list sends the build back to the host
+		coop = done;
+		c->grid_built_on_device = done;
+	}
+	if(!grid_on_device) {
+		if(have_grid) pt::build_grid(rec.data(), n, s.grid_hint, &gd, &cell_start, &cell_items);
+		item_total = cell_items.size();
+		if((rc = upload(c, c->cell_start, cell_start.data(), cell_start.size() * 4))) return rc;
+		if((rc = upload(c, c->cell_items, cell_items.data(), cell_items.size() * 4))) return rc;
+		std::vector<uint32_t> ranges;
+		coop = pt::object_ranges(rec.data(), n, gd, &ranges);
+		if((rc = upload(c, c->obj_range, ranges.data(), ranges.size() * 4))) return rc;
 		// What the cooperative cast's collection step needs of a list entry, in 16 bytes: the bounding
 		// sphere (radius rounded up to its upper 16 bits), in which of the six neighbour cells the
 		// entity is listed as well (bits 3..8: -x +x -y +y -z +z), and its intersection kind (bits 0..2).
@@ -224,7 +283,6 @@ int prepare(pt_ctx* c) {
 
 	// image tiling and this context's partition
 	const int tiles_x = (s.width + 7) / 8, tiles_y = (s.height + 7) / 8;
-	const int tiles = tiles_x * tiles_y;
 	c->local_tiles = pt_partition_tiles(s.width, s.height, s.part_index, s.part_count);
 	const bool compact = s.part_count > 1;
 	c->fb_floats = compact ? (size_t)c->local_tiles * 64 * 3 : (size_t)s.width * s.height * 3;
@@ -320,7 +378,7 @@ int prepare(pt_ctx* c) {
 	st.samples_total = (int)samples.size();
 	st.objects = n;
 	for(int k = 0; k < 3; k++) { st.cells[k] = gd.cell_count[k]; st.cell_size[k] = gd.cell_size[k]; }
-	st.cell_items = (int)cell_items.size();
+	st.cell_items = (int)item_total;
 	PT_HIP(c, hipStreamSynchronize(c->stream));
 	st.prepare_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 	c->prepared = true;
@@ -454,7 +512,7 @@ void pt_destroy(pt_ctx* c) {
 	if(c->active.load()) { *c->abort_flag = 1; join_worker(c); }
 	(void)hipSetDevice(c->device);
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
-	for(DevBuf* b : { &c->geo, &c->cell_start, &c->cell_items, &c->cell_entries, &c->obj_range, &c->partial, &c->fracs, &c->dirs, &c->disc, &c->samples, &c->offsets, &c->frame_dev, &c->fb, &c->accum, &c->counter, &c->stats_dev, &c->scratch }) b->release();
+	for(DevBuf* b : { &c->geo, &c->cell_start, &c->cell_items, &c->cell_entries, &c->obj_range, &c->partial, &c->fracs, &c->bbox, &c->grid_cursor, &c->grid_sums, &c->dirs, &c->disc, &c->samples, &c->offsets, &c->frame_dev, &c->fb, &c->accum, &c->counter, &c->stats_dev, &c->scratch }) b->release();
 	for(auto& p : c->pending) for(hipEvent_t e : p) (void)hipEventDestroy(e);
 	for(hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
 	if(c->abort_flag) (void)hipHostFree(c->abort_flag);
@@ -684,6 +742,29 @@ int pt_debug_coop_stats(pt_ctx* c, unsigned long long* out16) {
 	PT_HIP(c, hipSetDevice(c->device));
 	PT_HIP(c, hipDeviceSynchronize());
 	return ptl::coop_stats(out16);
+}
+
+int pt_debug_grid(pt_ctx* c, uint32_t* cell_start, int cell_capacity, uint32_t* cell_items, int item_capacity, uint32_t* obj_range,
+                  int* cell_total, int* item_total, int* built_on_device) {
+	if(!c) return PT_ERR_ARG;
+	if(!c->prepared) return fail(c, PT_ERR_STATE, "pt_debug_grid before pt_prepare");
+	PT_HIP(c, hipSetDevice(c->device));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	const size_t cells = (size_t)c->stats.cells[0] * (size_t)c->stats.cells[1] * (size_t)c->stats.cells[2];
+	const size_t items = (size_t)c->stats.cell_items;
+	if(cell_total) *cell_total = (int)cells;
+	if(item_total) *item_total = (int)items;
+	if(built_on_device) *built_on_device = c->grid_built_on_device ? 1 : 0;
+	if(cell_start) {
+		if((size_t)cell_capacity < cells + 1) return fail(c, PT_ERR_LIMIT, "cell_start needs %zu words", cells + 1);
+		PT_HIP(c, hipMemcpy(cell_start, c->cell_start.p, (cells + 1) * 4, hipMemcpyDeviceToHost));
+	}
+	if(cell_items && items > 0) {
+		if((size_t)item_capacity < items) return fail(c, PT_ERR_LIMIT, "cell_items needs %zu words", items);
+		PT_HIP(c, hipMemcpy(cell_items, c->cell_items.p, items * 4, hipMemcpyDeviceToHost));
+	}
+	if(obj_range && c->stats.objects > 0) PT_HIP(c, hipMemcpy(obj_range, c->obj_range.p, (size_t)c->stats.objects * 8, hipMemcpyDeviceToHost));
+	return PT_OK;
 }
 
 int pt_sample_ranges(const pt_settings* s) {

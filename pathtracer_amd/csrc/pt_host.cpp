@@ -275,8 +275,7 @@ static inline int clamp_cell(int v, int hi) {   // clampInt goes through the flo
 	return (int)(f > h ? h : f);
 }
 
-bool build_grid(const float* records, int n, int hint, GridDesc* g, std::vector<uint32_t>* cell_start,
-                std::vector<uint32_t>* cell_items) {
+bool grid_desc(const float* records, int n, int hint, GridDesc* g) {
 	float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
 	for(int i = 0; i < n; i++) {
 		const float* r = records + (size_t)i * PT_F_STRIDE;
@@ -301,6 +300,13 @@ bool build_grid(const float* records, int n, int hint, GridDesc* g, std::vector<
 	for(int k = 0; k < 3; k++) g->cell_count[k] = cmax[k] - g->coord_min[k];
 	int64_t cells = g->cells();
 	if(g->cell_count[0] <= 0 || g->cell_count[1] <= 0 || g->cell_count[2] <= 0 || cells > (1LL << 28)) return false;
+	return true;
+}
+
+bool build_grid(const float* records, int n, int hint, GridDesc* g, std::vector<uint32_t>* cell_start,
+                std::vector<uint32_t>* cell_items) {
+	if(!grid_desc(records, n, hint, g)) return false;
+	const int64_t cells = g->cells();
 
 	// inclusive cell range of an object's box (code/app.cpp:1297-1312)
 	auto range = [&](const float* r, int* a, int* b) {

@@ -41,6 +41,8 @@ void world_consts(const pt_world& w, int width, int height, WorldConsts* out);
 void make_tables(Pcg& rng, f3* dirs, f2* disc);
 // Blue-noise samples bucketed per pixel tile; offsets has grid_width^2+1 entries.
 void make_samples(Pcg& rng, int spp_wanted, int grid_width, std::vector<f2>* samples, std::vector<int32_t>* offsets);
+// Grid dimensions alone (spatialGridInit, code/raycast.cpp:595-617).
+bool grid_desc(const float* records, int n, int hint, GridDesc* g);
 // Returns false when the scene has no finite extent or the grid would exceed 2^28 cells.
 bool build_grid(const float* records, int n, int hint, GridDesc* g, std::vector<uint32_t>* cell_start,
                 std::vector<uint32_t>* cell_items);

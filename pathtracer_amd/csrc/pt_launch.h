@@ -67,6 +67,23 @@ hipError_t launch_cast(const SceneDev& sc, const float* origins, const float* di
 hipError_t launch_srgb8(const float* rgb, size_t n, uint8_t* out, hipStream_t stream);
 // Tile-major partition buffers (part_count of them, each `stride` floats apart) -> row-major image.
 hipError_t launch_assemble(const float* parts, size_t stride, int part_count, int width, int height, float* rgb, hipStream_t stream);
+// Device-side grid build (pt_gridbuild.hip).
+struct GridBuildJob {
+	const float4* geo;          // entity records (position | bounding radius in slot 0, type + flags in slot 3)
+	const float4* bbox;         // world-space bounding-box extents of every entity
+	int n;
+	GridDev grid;
+	uint32_t* obj_range;        // out: 2 words per entity
+	uint32_t* cell_start;       // out: cells + 1 words
+	uint32_t* cursor;           // scratch: cells words
+	uint32_t* block_sums;       // scratch: grid_scan_blocks(cells) words
+	uint32_t* cell_items;       // out (second pass)
+	float4* cell_entries;       // out (second pass), may be null
+	uint32_t* longest;          // out: length of the longest list (one word)
+};
+size_t grid_scan_blocks(size_t cells);
+hipError_t launch_grid_count_scan(const GridBuildJob& job, size_t cells, hipStream_t stream);
+hipError_t launch_grid_fill(const GridBuildJob& job, size_t cells, hipStream_t stream);
 const char* trace_kernel_name();
 int coop_stats(unsigned long long* out16);
 

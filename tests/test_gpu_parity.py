@@ -346,6 +346,34 @@ def test_grid_scenes_at_full_size(gpu, name):
     assert np.abs(got.astype(np.float64) - want).mean() < 1e-6
 
 
+@pytest.mark.parametrize("name", ["mixed40", "crowded", "dense2k", "dense30k"])
+def test_grid_built_on_device_equals_host_build(gpu, name, monkeypatch):
+    """The device passes (count, scan, fill, order) must give the host build's CSR word for word (ascending
+    ids per cell, the reference's append order), the same packed cell ranges, and therefore the same image;
+    the host build itself is pinned to the reference's lists in the CPU tests."""
+    if name == "dense30k":
+        world, objs = scenes.dense_scene(n=30000, seed=11, half_extent=120.0, height=60.0)
+        st = default_settings(96, 54, 4, 8, seed=77, grid_hint=40)
+    else:
+        world, objs = CASES[name][0]()
+        st = settings_for(name, 96, 54, 4, 8)
+    got = {}
+    for where in ("host", "device"):
+        monkeypatch.setenv("PT_GRID_BUILD", where)
+        img = gpu.render(world, objs, st)
+        start, lists, ranges, on_device = gpu.debug_grid()
+        assert on_device == (where == "device")
+        got[where] = (start, lists, ranges, img)
+    monkeypatch.delenv("PT_GRID_BUILD")
+    for a, b in zip(got["host"][:3], got["device"][:3]):
+        assert a.shape == b.shape and (a == b).all()
+    assert (bits(got["host"][3]) == bits(got["device"][3])).all()
+    sc = OracleScene(world, objs, st)
+    _, cs, ci = sc.grid()
+    sc.close()
+    assert (cs == got["device"][0]).all() and (ci == got["device"][1]).all()
+
+
 def test_zero_sample_tile_is_black(gpu):
     world, objs = scenes.default_scene()
     for seed in range(40):
