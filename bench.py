@@ -167,23 +167,16 @@ def main():
 
     stream = torch.cuda.current_stream()
     if world_size > 1:
-        # tile-major partition buffers; rank 0 gathers them and assembles the image
-        stride = ptdist.partition_stride(st.width, st.height, world_size)
-        assert part_floats <= stride
-        mine = torch.zeros(stride, dtype=torch.float32, device="cuda")
-        gathered = torch.empty(world_size * stride, dtype=torch.float32, device="cuda") if rank == 0 else None
-        image = torch.empty(st.height * st.width * 3, dtype=torch.float32, device="cuda") if rank == 0 else None
+        # tile-major partition buffers; rank 0 gathers them and assembles the image on a side stream while
+        # the next frame is traced
+        pipe = ptdist.FramePipeline([r], [rank], world_size, st.width, st.height, rank, world_size)
+        assert part_floats <= pipe.stride
+        step = pipe.step
     else:
         image = torch.empty(st.height * st.width * 3, dtype=torch.float32, device="cuda")
 
-    def step():
-        if world_size == 1:
+        def step():
             r.trace(d_rgb=image.data_ptr(), stream=stream.cuda_stream, sync=False)
-        else:
-            r.trace(d_rgb=mine.data_ptr(), stream=stream.cuda_stream, sync=False)
-            ptdist.gather_parts(mine, gathered, stride, rank, world_size)
-            if rank == 0:
-                r.assemble(gathered.data_ptr(), stride, world_size, st.width, st.height, image.data_ptr(), stream.cuda_stream)
 
     for _ in range(args.warmup):
         step()

@@ -26,3 +26,49 @@ def gather_parts(mine, gathered, stride, rank, world_size, root=0, group=None):
         dist.gather(mine, views, dst=root, group=group)
     else:
         dist.gather(mine, None, dst=root, group=group)
+
+
+class FramePipeline:
+    """Frames of a partitioned render with the gather off the critical path: the tile buffers are
+    double-buffered, the trace of frame i+1 runs on the main stream while the gather and the assemble of
+    frame i run on a side stream.  `renderers` are this process's contexts (one per owned partition; one
+    in the one-process-per-GPU case), `parts` their partition indices."""
+
+    def __init__(self, renderers, parts, part_count, width, height, rank=0, world_size=1, group=None):
+        self.renderers, self.parts, self.part_count = renderers, parts, part_count
+        self.width, self.height, self.rank, self.world_size, self.group = width, height, rank, world_size, group
+        self.stride = partition_stride(width, height, part_count)
+        self.main = torch.cuda.current_stream()
+        self.side = torch.cuda.Stream()
+        local = len(parts)
+        self.mine = [torch.zeros(local * self.stride, dtype=torch.float32, device="cuda") for _ in range(2)]
+        root = rank == 0
+        self.gathered = [torch.empty(part_count * self.stride, dtype=torch.float32, device="cuda") if root else None for _ in range(2)]
+        self.image = torch.empty(height * width * 3, dtype=torch.float32, device="cuda") if root else None
+        self.traced = [torch.cuda.Event() for _ in range(2)]
+        self.drained = [torch.cuda.Event() for _ in range(2)]
+        self.frame = 0
+
+    def step(self):
+        b = self.frame & 1
+        if self.frame >= 2:
+            self.main.wait_event(self.drained[b])          # the gather that read mine[b] two frames ago
+        for k, r in enumerate(self.renderers):
+            r.trace(d_rgb=self.mine[b][k * self.stride:].data_ptr(), stream=self.main.cuda_stream, sync=False)
+        self.traced[b].record(self.main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.traced[b])
+            if self.world_size > 1:
+                gather_parts(self.mine[b], self.gathered[b], self.stride, self.rank, self.world_size, group=self.group)
+            else:                                           # one process owns several partitions: place them by index
+                for k, p in enumerate(self.parts):
+                    self.gathered[b][p * self.stride:(p + 1) * self.stride].copy_(self.mine[b][k * self.stride:(k + 1) * self.stride])
+            if self.rank == 0:
+                self.renderers[0].assemble(self.gathered[b].data_ptr(), self.stride, self.part_count, self.width, self.height,
+                                           self.image.data_ptr(), self.side.cuda_stream)
+            self.drained[b].record(self.side)
+        self.frame += 1
+
+    def finish(self):
+        torch.cuda.synchronize()
+        return self.image

@@ -251,6 +251,29 @@ def test_assemble_on_device(gpu):
         assert (bits(got) == bits(whole)).all(), parts
 
 
+def test_pipelined_partition_frames(gpu):
+    """The double-buffered frame pipeline of the multi-GPU bench (trace on the main stream, gather and
+    assemble of the previous frame on a side stream), run here with three partitions owned by one
+    process: every frame's assembled image equals the unpartitioned render bit for bit."""
+    torch = pytest.importorskip("torch")
+    from pathtracer_amd import dist as ptdist
+    world, objs = scenes.mixed_scene(seed=7, n=40)
+    st = settings_for("mixed40", 200, 120, 8, 8)
+    whole = gpu.render(world, objs, st)
+    parts = []
+    for p in range(3):
+        r = api.Renderer(0)
+        r.prepare(world, objs, settings_for("mixed40", 200, 120, 8, 8, part_index=p, part_count=3))
+        parts.append(r)
+    pipe = ptdist.FramePipeline(parts, [0, 1, 2], 3, 200, 120)
+    for frame in range(5):
+        pipe.step()
+    img = pipe.finish().cpu().numpy().reshape(120, 200, 3)
+    for r in parts:
+        r.close()
+    assert (bits(img) == bits(whole)).all()
+
+
 def test_headless_harness(gpu, tmp_path):
     """The C++ harness drives start / progress / wait through the C ABI and writes the image."""
     import json
