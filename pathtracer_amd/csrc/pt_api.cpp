@@ -63,6 +63,12 @@ struct pt_ctx {
 	ptl::TraceJob job{};
 	size_t fb_floats = 0;
 	bool grid_built_on_device = false;
+	// random tables and blue-noise samples kept between renders (they depend on seed, spp_wanted, sample_grid_width)
+	bool tables_valid = false;
+	uint64_t tables_seed = 0;
+	int tables_spp = 0, tables_grid_w = 0;
+	std::vector<pt::f2> samples_host;
+	std::vector<int32_t> offsets_host;
 	uint32_t serial = 0;        // launch counter: marks the range sums each launch writes
 	int local_tiles = 0;
 
@@ -126,7 +132,6 @@ int upload(pt_ctx* c, DevBuf& b, const void* src, size_t bytes) {
 	return PT_OK;
 }
 
-// pt_prepare body; the caller holds no lock and has set the device.
 // Per-cell lists, entity cell ranges and the cooperative cast's list entries built on the device
 // (pt_gridbuild.hip) from the uploaded entity records.  *done is false when a cell lists more than
 // kLongestDeviceList entities: the ordering pass sorts a list with one thread, so the host builds then.
@@ -168,6 +173,7 @@ int grid_build_device(pt_ctx* c, const std::vector<float>& rec, int n, const pt:
 	return PT_OK;
 }
 
+// pt_prepare body; the caller holds no lock and has set the device.
 int prepare(pt_ctx* c) {
 	auto t0 = std::chrono::steady_clock::now();
 	const pt_settings& s = c->st;
@@ -178,15 +184,23 @@ int prepare(pt_ctx* c) {
 	pt::WorldConsts wc;
 	pt::world_consts(c->world, s.width, s.height, &wc);
 
-	// tables, then blue noise, from PCG stream (0, seed): the order the application draws them in
-	pt::Pcg rng;
-	rng.seed(0, s.seed);
-	std::vector<pt::f3> dirs(PT_TABLE_COUNT);
-	std::vector<pt::f2> disc(PT_TABLE_COUNT);
-	pt::make_tables(rng, dirs.data(), disc.data());
-	std::vector<pt::f2> samples;
-	std::vector<int32_t> offsets;
-	pt::make_samples(rng, s.spp_wanted, s.sample_grid_width, &samples, &offsets);
+	// tables, then blue noise, from PCG stream (0, seed): the order the application draws them in.
+	// They depend on three settings only, so a context keeps them (host and device copies) from one
+	// render to the next, as the application keeps its tables from start-up (code/app.cpp:669-727).
+	const bool tables_kept = c->tables_valid && c->tables_seed == s.seed && c->tables_spp == s.spp_wanted && c->tables_grid_w == s.sample_grid_width;
+	std::vector<pt::f2>& samples = c->samples_host;
+	std::vector<int32_t>& offsets = c->offsets_host;
+	std::vector<pt::f3> dirs;
+	std::vector<pt::f2> disc;
+	if(!tables_kept) {
+		c->tables_valid = false;
+		pt::Pcg rng;
+		rng.seed(0, s.seed);
+		dirs.resize(PT_TABLE_COUNT);
+		disc.resize(PT_TABLE_COUNT);
+		pt::make_tables(rng, dirs.data(), disc.data());
+		pt::make_samples(rng, s.spp_wanted, s.sample_grid_width, &samples, &offsets);
+	}
 	for(size_t t = 0; t + 1 < offsets.size(); t++)
 		if(offsets[t + 1] - offsets[t] > 4096) return fail(c, PT_ERR_LIMIT, "a pixel tile holds %d samples, more than the 4096 the per-sample streams allow", offsets[t + 1] - offsets[t]);
 
@@ -225,8 +239,6 @@ int prepare(pt_ctx* c) {
 		float* m0 = slot(6); m0[0] = r[PT_F_COLOR]; m0[1] = r[PT_F_COLOR + 1]; m0[2] = r[PT_F_COLOR + 2]; m0[3] = r[PT_F_REFL];
 		float* m1 = slot(7); m1[0] = r[PT_F_EMIT]; m1[1] = r[PT_F_EMIT + 1]; m1[2] = r[PT_F_EMIT + 2]; m1[3] = r[PT_F_IOR];
 	}
-	std::vector<float> dirs4((size_t)PT_TABLE_COUNT * 4, 0.0f);
-	for(int i = 0; i < PT_TABLE_COUNT; i++) { dirs4[(size_t)i * 4] = dirs[(size_t)i].x; dirs4[(size_t)i * 4 + 1] = dirs[(size_t)i].y; dirs4[(size_t)i * 4 + 2] = dirs[(size_t)i].z; }
 
 	int rc;
 	if((rc = upload(c, c->geo, geo.data(), geo.size() * 4))) return rc;
@@ -276,10 +288,16 @@ int prepare(pt_ctx* c) {
 		}
 		if((rc = upload(c, c->cell_entries, entries.data(), entries.size() * 4))) return rc;
 	}
-	if((rc = upload(c, c->dirs, dirs4.data(), dirs4.size() * 4))) return rc;
-	if((rc = upload(c, c->disc, disc.data(), disc.size() * sizeof(pt::f2)))) return rc;
-	if((rc = upload(c, c->samples, samples.data(), samples.size() * sizeof(pt::f2)))) return rc;
-	if((rc = upload(c, c->offsets, offsets.data(), offsets.size() * 4))) return rc;
+	if(!tables_kept) {
+		std::vector<float> dirs4((size_t)PT_TABLE_COUNT * 4, 0.0f);
+		for(int i = 0; i < PT_TABLE_COUNT; i++) { dirs4[(size_t)i * 4] = dirs[(size_t)i].x; dirs4[(size_t)i * 4 + 1] = dirs[(size_t)i].y; dirs4[(size_t)i * 4 + 2] = dirs[(size_t)i].z; }
+		if((rc = upload(c, c->dirs, dirs4.data(), dirs4.size() * 4))) return rc;
+		if((rc = upload(c, c->disc, disc.data(), disc.size() * sizeof(pt::f2)))) return rc;
+		if((rc = upload(c, c->samples, samples.data(), samples.size() * sizeof(pt::f2)))) return rc;
+		if((rc = upload(c, c->offsets, offsets.data(), offsets.size() * 4))) return rc;
+		c->tables_seed = s.seed; c->tables_spp = s.spp_wanted; c->tables_grid_w = s.sample_grid_width;
+		c->tables_valid = true;
+	}
 
 	// image tiling and this context's partition
 	const int tiles_x = (s.width + 7) / 8, tiles_y = (s.height + 7) / 8;
@@ -363,15 +381,24 @@ int prepare(pt_ctx* c) {
 	st = pt_stats{};
 	const int gw = s.sample_grid_width;
 	uint64_t paths = 0, pixels = 0, empty = 0;
-	for(int lt = 0; lt < c->local_tiles; lt++) {
-		int tile = lt * s.part_count + s.part_index;
-		int x0 = (tile % tiles_x) * 8, y0 = (tile / tiles_x) * 8;
-		for(int yy = y0; yy < y0 + 8 && yy < s.height; yy++) for(int xx = x0; xx < x0 + 8 && xx < s.width; xx++) {
-			int t = (yy % gw) * gw + (xx % gw);
-			int cnt = offsets[(size_t)t + 1] - offsets[(size_t)t];
-			pixels++;
-			if(cnt == 0) empty++;
-			else paths += s.frame_index >= 0 ? 1u : (uint64_t)cnt;
+	auto tally = [&](int t, uint64_t count) {
+		int cnt = offsets[(size_t)t + 1] - offsets[(size_t)t];
+		pixels += count;
+		if(cnt == 0) empty += count;
+		else paths += count * (s.frame_index >= 0 ? 1u : (uint64_t)cnt);
+	};
+	if(s.part_count == 1) {
+		// the whole image: pixels per blue-noise bucket = columns with x % gw == rx times rows with y % gw == ry
+		for(int ry = 0; ry < gw; ry++) for(int rx = 0; rx < gw; rx++) {
+			uint64_t cols = (uint64_t)((s.width - rx + gw - 1) / gw), rows = (uint64_t)((s.height - ry + gw - 1) / gw);
+			if(rx < s.width && ry < s.height) tally(ry * gw + rx, cols * rows);
+		}
+	} else {
+		for(int lt = 0; lt < c->local_tiles; lt++) {
+			int tile = lt * s.part_count + s.part_index;
+			int x0 = (tile % tiles_x) * 8, y0 = (tile / tiles_x) * 8;
+			for(int yy = y0; yy < y0 + 8 && yy < s.height; yy++) for(int xx = x0; xx < x0 + 8 && xx < s.width; xx++)
+				tally((yy % gw) * gw + (xx % gw), 1);
 		}
 	}
 	st.paths = paths; st.pixels = pixels; st.zero_sample_pixels = empty;
