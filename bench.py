@@ -46,8 +46,10 @@ FLOP_WEIGHTS = {
     "lens": 40,
 }
 PEAK_FP32_VALU_TFLOPS = 157.3      # MI355X vector fp32 peak: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz x 2 (FMA) x 2 (packed)
-PEAK_SCALAR_ISSUE_TFLOPS = 39.3    # the same lanes issuing one plain add/mul per lane and cycle: what code that must
-                                   # round every operation like the reference (no FMA contraction, no packing) can reach
+PEAK_SCALAR_ISSUE_TFLOPS = 78.6    # the same machine issuing plain (unfused, unpacked) adds and multiplies, one wave64
+                                   # instruction per SIMD every 2 cycles: the ceiling of code that must round every
+                                   # operation like the reference; profiles/micro/valu_rate measures 58.6 (4 waves per
+                                   # SIMD) to 66.2 (8 waves) T lane-ops/s of it
 # flop/path of the named workloads as counted by the CPU leg (oracle event counters x FLOP_WEIGHTS); used
 # when the CPU leg is skipped (--no-cpu, more than one GPU) so that the roofline block is always filled
 KNOWN_FLOPS_PER_PATH = {"demo-1080p-64spp-d8": 259.5531495662587}
