@@ -56,7 +56,7 @@ struct pt_ctx {
 	bool prepared = false;
 
 	// device-resident scene
-	DevBuf geo, cell_start, cell_items, cell_entries, obj_range, partial, fracs, bbox, grid_cursor, grid_sums, dirs, disc, samples, offsets, frame_dev, fb, accum, counter, stats_dev, scratch;
+	DevBuf geo, cell_start, cell_items, cell_entries, obj_range, partial, fracs, bbox, grid_cursor, grid_sums, tile_cost, tile_order, dirs, disc, samples, offsets, frame_dev, fb, accum, counter, stats_dev, scratch;
 	uint32_t* abort_flag = nullptr;      // host-pinned, read by the trace kernel
 	uint32_t* abort_flag_dev = nullptr;  // the same word as the device addresses it
 	uint32_t* counter_host = nullptr;    // host-pinned landing word for progress polls
@@ -376,6 +376,25 @@ int prepare(pt_ctx* c) {
 	j.frame_index = s.frame_index;
 	j.compact = compact ? 1 : 0;
 
+	// The order tiles are dealt in: dearest first by an estimate from one probe path per pixel, so that
+	// the frame's last work items are cheap ones (a frame that ends on its dearest tiles idles most of the
+	// chip meanwhile).  Equal estimates go bottom-up: the lower rows of an image are usually the busier.
+	j.tile_order = nullptr;
+	if(c->local_tiles > 1 && getenv("PT_TILE_ORDER_INDEX") == nullptr) {
+		PT_HIP(c, c->tile_cost.reserve((size_t)c->local_tiles * 2));
+		PT_HIP(c, ptl::launch_tile_cost(j, c->local_tiles, c->tile_cost.as<uint16_t>(), c->stream));
+		std::vector<uint16_t> cost((size_t)c->local_tiles);
+		PT_HIP(c, hipMemcpyAsync(cost.data(), c->tile_cost.p, cost.size() * 2, hipMemcpyDeviceToHost, c->stream));
+		PT_HIP(c, hipStreamSynchronize(c->stream));
+		std::vector<size_t> first(1025, 0);           // counting sort: descending cost, descending index within a cost
+		for(uint16_t v : cost) first[1023 - (v > 1023 ? 1023 : v) + 1]++;
+		for(int k = 1; k < 1025; k++) first[k] += first[k - 1];
+		std::vector<int32_t> order(cost.size());
+		for(size_t t = cost.size(); t-- > 0;) order[first[1023 - (cost[t] > 1023 ? 1023 : cost[t])]++] = (int32_t)t;
+		if((rc = upload(c, c->tile_order, order.data(), order.size() * 4))) return rc;
+		j.tile_order = c->tile_order.as<int32_t>();
+	}
+
 	// exact path count of this partition (code/raycast.cpp:1045-1048 summed over its pixels)
 	pt_stats& st = c->stats;
 	st = pt_stats{};
@@ -539,7 +558,7 @@ void pt_destroy(pt_ctx* c) {
 	if(c->active.load()) { *c->abort_flag = 1; join_worker(c); }
 	(void)hipSetDevice(c->device);
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
-	for(DevBuf* b : { &c->geo, &c->cell_start, &c->cell_items, &c->cell_entries, &c->obj_range, &c->partial, &c->fracs, &c->bbox, &c->grid_cursor, &c->grid_sums, &c->dirs, &c->disc, &c->samples, &c->offsets, &c->frame_dev, &c->fb, &c->accum, &c->counter, &c->stats_dev, &c->scratch }) b->release();
+	for(DevBuf* b : { &c->geo, &c->cell_start, &c->cell_items, &c->cell_entries, &c->obj_range, &c->partial, &c->fracs, &c->bbox, &c->grid_cursor, &c->grid_sums, &c->tile_cost, &c->tile_order, &c->dirs, &c->disc, &c->samples, &c->offsets, &c->frame_dev, &c->fb, &c->accum, &c->counter, &c->stats_dev, &c->scratch }) b->release();
 	for(auto& p : c->pending) for(hipEvent_t e : p) (void)hipEventDestroy(e);
 	for(hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
 	if(c->abort_flag) (void)hipHostFree(c->abort_flag);

@@ -130,7 +130,8 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 				}
 				g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
 				if(g >= (uint32_t)job.n_groups) { dry = true; break; }
-				const int local_tile = (int)(g >> ranges_log2);
+				// tiles are dealt in the order of the host's cost estimate, dearest first, so that the frame ends on cheap ones
+				const int local_tile = job.tile_order ? job.tile_order[g >> ranges_log2] : (int)(g >> ranges_log2);
 				const int tile = local_tile * job.part_count + job.part_index;
 				tile_range = (int)(g & ((1u << ranges_log2) - 1u));
 				tile_x0 = (tile % job.tiles_x) * 8;
@@ -301,6 +302,43 @@ __global__ __launch_bounds__(kBlock) void pt_k_resolve(ptl::TraceJob job, size_t
 	}
 }
 
+// Cost estimate of every owned 8x8 tile, for the order the trace kernel deals them in: the ray casts of
+// one whole path per pixel (camera sample 0, traced and shaded exactly as the trace kernel does), one
+// wavefront per tile.  Only scheduling depends on it.
+__global__ __launch_bounds__(kBlock) void pt_k_tile_cost(ptl::TraceJob job, int local_tiles, uint16_t* cost) {
+	const int lt = blockIdx.x * (kBlock / 64) + (int)threadIdx.x / 64;
+	if(lt >= local_tiles) return;
+	const Scene sc = scene_view(job.scene);
+	const FrameRef fr = (FrameRef)job.frame;
+	const int lane = lane_id();
+	const int tile = lt * job.part_count + job.part_index;
+	const int x = (tile % job.tiles_x) * 8 + (lane & 7), y = (tile / job.tiles_x) * 8 + (lane >> 3);
+	uint32_t casts = 0;
+	if(x < fr->width && y < fr->height) {
+		const int t = (y % fr->tile_w) * fr->tile_w + (x % fr->tile_w);
+		const int base = sc.offsets[t];
+		if(sc.offsets[t + 1] != base) {
+			V3 rp, rd;
+			const int lens = fr->aperture != 0.0f ? lens_start(fr, x, y) : 0;
+			camera_ray(sc, fr, pixel_origin(fr, x, y), sc.samples[base], lens, rp, rd);
+			Rng rng;
+			sample_stream(fr, x, y, 0, 0, rng);
+			V3 att = v3(1, 1, 1), col = v3(0, 0, 0);
+			for(int bounce = 0; bounce < fr->max_bounces; bounce++) {
+				V3 hp = v3(0, 0, 0), hn = v3(0, 0, 0);
+				uint64_t unused = 0;
+				Surface surf;
+				surf.m0 = (v4f)(0.0f); surf.m1 = (v4f){ 0.0f, 0.0f, 0.0f, 1.0f }; surf.rough = 0;
+				const int id = cast<false>(sc, rp, rd, hp, hn, surf, unused);
+				casts++;
+				if(!shade(sc, fr, id, surf, hp, hn, bounce, rp, rd, att, col, rng)) break;
+			}
+		}
+	}
+	for(int off = 32; off > 0; off >>= 1) casts += __shfl_down(casts, off, 64);
+	if(lane == 0) cost[lt] = (uint16_t)(casts > 1023u ? 1023u : casts);
+}
+
 // Debug pass: entity hit by, and grid cells visited by, the primary ray of camera sample 0 of
 // every pixel.  Same device functions as the trace kernel.
 __global__ __launch_bounds__(kBlock) void pt_k_primary(ptl::SceneDev scene, const ptl::FrameDev* frame, int32_t* hit_id, uint64_t* cell_hash) {
@@ -418,6 +456,13 @@ hipError_t launch_trace(const TraceJob& job, hipStream_t stream, int* grid_block
 	if(mode == CAST_BRUTE) hipLaunchKernelGGL(pt_k_trace<CAST_BRUTE>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
 	else if(mode == CAST_GRID_LANE) hipLaunchKernelGGL(pt_k_trace<CAST_GRID_LANE>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
 	else hipLaunchKernelGGL(pt_k_trace<CAST_GRID_COOP>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
+	return hipGetLastError();
+}
+
+hipError_t launch_tile_cost(const TraceJob& job, int local_tiles, uint16_t* cost, hipStream_t stream) {
+	if(local_tiles <= 0) return hipSuccess;
+	const int per_block = kBlock / 64;
+	hipLaunchKernelGGL(pt_k_tile_cost, dim3((unsigned)((local_tiles + per_block - 1) / per_block)), dim3(kBlock), 0, stream, job, local_tiles, cost);
 	return hipGetLastError();
 }
 
