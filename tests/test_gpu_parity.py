@@ -397,6 +397,23 @@ def test_grid_built_on_device_equals_host_build(gpu, name, monkeypatch):
     assert (cs == got["device"][0]).all() and (ci == got["device"][1]).all()
 
 
+@pytest.mark.parametrize("w,h,spp", [(1, 1, 16), (8, 8, 4), (9, 17, 64), (24, 8, 4), (300, 7, 128)])
+def test_small_and_ragged_images(gpu, w, h, spp):
+    """Images smaller than a work group, with ragged edge tiles, or smaller than the reference's own tile
+    jobs can describe (its job size is (int)sqrt(W*H/204), zero below 204 pixels): the oracle renders them
+    as one rectangle."""
+    world, objs = scenes.default_scene()
+    st = default_settings(w, h, spp, 8, seed=5)
+    img = gpu.render(world, objs, st)
+    sc = OracleScene(world, objs, st)
+    ref = np.zeros((h, w, 3), np.float32)
+    sc.lib.pto_render_rect(sc.h, 0, 3, 0, 0, w, h, P(ref))
+    paths = sc.path_count()
+    sc.close()
+    assert gpu.stats().paths == paths
+    assert (bits(img) == bits(ref)).all()
+
+
 def test_zero_sample_tile_is_black(gpu):
     world, objs = scenes.default_scene()
     for seed in range(40):
