@@ -604,7 +604,7 @@ constexpr int COOP_CELLS = PT_COOP_CELLS;               // cells a lane records 
 #define PT_COOP_DESCS 360
 #endif
 constexpr int COOP_POOL = PT_COOP_POOL;                 // candidates awaiting their intersection test
-constexpr int COOP_DESCS = PT_COOP_DESCS;               // non-empty cells the wavefront can note per segment (at most 511)
+constexpr int COOP_DESCS = PT_COOP_DESCS;               // non-empty cells the wavefront can note per segment
 constexpr int COOP_MIN_WALKING = PT_COOP_MIN_WALKING;   // fewer walking lanes than this: return and refill
 #ifndef PT_COOP_ITEMS
 #define PT_COOP_ITEMS 2
