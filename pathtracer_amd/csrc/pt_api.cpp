@@ -376,7 +376,7 @@ int prepare(pt_ctx* c) {
 	j.frame_index = s.frame_index;
 	j.compact = compact ? 1 : 0;
 
-	// The order tiles are dealt in: dearest first by an estimate from one probe path per pixel, so that
+	// The order tiles are dealt in: dearest first by an estimate from sixteen probe paths per tile, so that
 	// the frame's last work items are cheap ones (a frame that ends on its dearest tiles idles most of the
 	// chip meanwhile).  Equal estimates go bottom-up: the lower rows of an image are usually the busier.
 	j.tile_order = nullptr;

@@ -303,18 +303,19 @@ __global__ __launch_bounds__(kBlock) void pt_k_resolve(ptl::TraceJob job, size_t
 }
 
 // Cost estimate of every owned 8x8 tile, for the order the trace kernel deals them in: the ray casts of
-// one whole path per pixel (camera sample 0, traced and shaded exactly as the trace kernel does), one
-// wavefront per tile.  Only scheduling depends on it.
+// sixteen whole paths (camera sample 0 of every second pixel in x and y, traced and shaded exactly as
+// the trace kernel does), four tiles per wavefront.  Only scheduling depends on it.
 __global__ __launch_bounds__(kBlock) void pt_k_tile_cost(ptl::TraceJob job, int local_tiles, uint16_t* cost) {
-	const int lt = blockIdx.x * (kBlock / 64) + (int)threadIdx.x / 64;
-	if(lt >= local_tiles) return;
+	const int lane = lane_id();
+	const int lt = (blockIdx.x * (kBlock / 64) + (int)threadIdx.x / 64) * 4 + (lane >> 4);
 	const Scene sc = scene_view(job.scene);
 	const FrameRef fr = (FrameRef)job.frame;
-	const int lane = lane_id();
-	const int tile = lt * job.part_count + job.part_index;
-	const int x = (tile % job.tiles_x) * 8 + (lane & 7), y = (tile / job.tiles_x) * 8 + (lane >> 3);
+	const bool owned = lt < local_tiles;
+	const int tile = (owned ? lt : 0) * job.part_count + job.part_index;
+	const int probe = lane & 15;
+	const int x = (tile % job.tiles_x) * 8 + (probe & 3) * 2 + ((probe >> 2) & 1), y = (tile / job.tiles_x) * 8 + (probe >> 2) * 2;
 	uint32_t casts = 0;
-	if(x < fr->width && y < fr->height) {
+	if(owned && x < fr->width && y < fr->height) {
 		const int t = (y % fr->tile_w) * fr->tile_w + (x % fr->tile_w);
 		const int base = sc.offsets[t];
 		if(sc.offsets[t + 1] != base) {
@@ -335,8 +336,8 @@ __global__ __launch_bounds__(kBlock) void pt_k_tile_cost(ptl::TraceJob job, int 
 			}
 		}
 	}
-	for(int off = 32; off > 0; off >>= 1) casts += __shfl_down(casts, off, 64);
-	if(lane == 0) cost[lt] = (uint16_t)(casts > 1023u ? 1023u : casts);
+	for(int off = 8; off > 0; off >>= 1) casts += __shfl_down(casts, off, 64);      // sum over the tile's 16 lanes
+	if(owned && probe == 0) cost[lt] = (uint16_t)(casts > 1023u ? 1023u : casts);
 }
 
 // Debug pass: entity hit by, and grid cells visited by, the primary ray of camera sample 0 of
@@ -461,7 +462,7 @@ hipError_t launch_trace(const TraceJob& job, hipStream_t stream, int* grid_block
 
 hipError_t launch_tile_cost(const TraceJob& job, int local_tiles, uint16_t* cost, hipStream_t stream) {
 	if(local_tiles <= 0) return hipSuccess;
-	const int per_block = kBlock / 64;
+	const int per_block = kBlock / 64 * 4;
 	hipLaunchKernelGGL(pt_k_tile_cost, dim3((unsigned)((local_tiles + per_block - 1) / per_block)), dim3(kBlock), 0, stream, job, local_tiles, cost);
 	return hipGetLastError();
 }

@@ -62,7 +62,7 @@ struct TraceJob {
 
 hipError_t launch_trace(const TraceJob& job, hipStream_t stream, int* grid_blocks_out);
 hipError_t launch_resolve(const TraceJob& job, size_t slots, hipStream_t stream);
-hipError_t launch_tile_cost(const TraceJob& job, int local_tiles, uint16_t* cost, hipStream_t stream);   // cost: ray casts of 64 probe paths per owned tile, at most 1023
+hipError_t launch_tile_cost(const TraceJob& job, int local_tiles, uint16_t* cost, hipStream_t stream);   // cost: ray casts of 16 probe paths per owned tile, at most 1023
 hipError_t launch_primary_aov(const SceneDev& sc, const FrameDev* fr, int width, int height, int32_t* hit_id, uint64_t* cell_hash, hipStream_t stream);
 hipError_t launch_cast(const SceneDev& sc, const float* origins, const float* dirs, int n, int32_t* hit_id,
                        float* hit_pos, float* hit_nrm, hipStream_t stream);
