@@ -221,6 +221,8 @@ def main():
                        "rays_per_frame_rank0": int(kstats.rays), "partition": f"8x8 tiles round-robin over {world_size} GPU(s)",
                        "seed_policy": "per-sample PCG32 streams"},
         }
+        # neither HBM (0.03 TB/s moved) nor MFMA (no dense contraction in a path tracer) bounds this kernel: the
+        # fp32 vector ALUs' instruction issue does, so the peak quoted is the vector fp32 peak
         roof = {"bound": "valu", "kernel": "pt_k_trace", "achieved": None, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                 "frac": None, "traffic": None, "kernel_ms": kernel_ms,
                 "kernel_ms_min": float(kstats.trace_ms_min), "kernel_ms_max": float(kstats.trace_ms_max)}
