@@ -601,7 +601,7 @@ constexpr int COOP_CELLS = PT_COOP_CELLS;               // cells a lane records 
 #define PT_COOP_POOL 256
 #endif
 #ifndef PT_COOP_DESCS
-#define PT_COOP_DESCS 360
+#define PT_COOP_DESCS 336
 #endif
 constexpr int COOP_POOL = PT_COOP_POOL;                 // candidates awaiting their intersection test
 constexpr int COOP_DESCS = PT_COOP_DESCS;               // non-empty cells the wavefront can note per segment
@@ -610,7 +610,11 @@ constexpr int COOP_MIN_WALKING = PT_COOP_MIN_WALKING;   // fewer walking lanes t
 #define PT_COOP_ITEMS 2
 #endif
 constexpr int COOP_ITEMS = PT_COOP_ITEMS;                 // list entries a lane expands per trip
-constexpr uint32_t COOP_SEQ_MAX = 1u << 20;                // list entries one segment can hold (20 bits of desc_at)
+#ifndef PT_COOP_HEAD_WORDS
+#define PT_COOP_HEAD_WORDS 32
+#endif
+constexpr int COOP_HEAD_WORDS = PT_COOP_HEAD_WORDS;       // words of the list-head bitmap (at most 64: one lane scans one word)
+constexpr uint32_t COOP_SEQ_MAX = 32u * COOP_HEAD_WORDS;  // list entries one segment can hold (a longer single list goes alone)
 static_assert(PT_COOP_CELLS <= 8, "the cell ordinal has three bits in a descriptor");
 #ifndef PT_COOP_MIX_ALL
 #define PT_COOP_MIX_ALL 128
@@ -635,6 +639,8 @@ struct CoopShared {                           // one per wavefront
 	unsigned long long work;                  // descriptors noted << 32 | list entries they cover
 	unsigned long long cutoff;                // first descriptor turned away << 32 | its sequence position
 	uint32_t desc_k0[COOP_DESCS];             // first entry of the cell's list
+	uint32_t head[COOP_HEAD_WORDS];           // bit p set: a list starts at position p of the flattened sequence
+	uint16_t rank0[COOP_HEAD_WORDS];          // lists that start before the word's first position
 	uint32_t desc_at[COOP_DESCS];             // position of that entry in the flattened sequence << 12 |
 	                                          // owner lane | cell ordinal << 6 | face the ray entered through << 9 (7: none)
 #ifdef PT_COOP_TIMING
@@ -842,6 +848,7 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 		// ---- reset the wavefront's bins --------------------------------------------------------
 		if(lane < KIND_COUNT + 2) { sh.count[lane] = 0; sh.fill[lane] = 0; }
 		if(lane == 0) { sh.work = 0; sh.cutoff = COOP_NONE; }
+		if(lane < COOP_HEAD_WORDS) sh.head[lane] = 0;
 		sh.best[lane] = COOP_NONE;
 		sh.ncell[lane] = 0;
 		wave_sync();
@@ -896,6 +903,7 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 								face = step == 1 ? 0u : step == -1 ? 1u : step == 1024 ? 2u : step == -1024 ? 3u : step > 0 ? 4u : 5u;
 							}
 							sh.desc_at[slot] = (start << 12) | (uint32_t)lane | ((uint32_t)j << 6) | (face << 9);
+							atomicOr(&sh.head[start >> 5], 1u << (start & 31u));       // start < COOP_SEQ_MAX for every accepted list
 						}
 					}
 					if(open) { sh.cells[j][lane] = cc[j]; recorded = j + 1; }
@@ -914,19 +922,28 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 		const uint32_t refused = uniform((uint32_t)(cutoff >> 32));
 		const uint32_t ndesc = noted < refused ? noted : refused;
 		const uint32_t total = uniform(cutoff != COOP_NONE ? (uint32_t)cutoff : (uint32_t)work);
-		// search depth: the highest power of two below the number of descriptors (wave-uniform)
-		const uint32_t top = ndesc > 1 ? 1u << (31 - __builtin_clz(ndesc - 1)) : 0u;
+		// Which list an entry position belongs to: descriptors are in position order, so it is the number of
+		// list heads at or before the position, less one - a prefix count per bitmap word plus a popcount.
+		{
+			const uint32_t mine = lane < COOP_HEAD_WORDS ? (uint32_t)__popc(sh.head[lane < COOP_HEAD_WORDS ? lane : 0]) : 0u;
+			uint32_t upto = mine;
+			for(int off = 1; off < COOP_HEAD_WORDS; off <<= 1) {
+				const uint32_t below = __shfl_up(upto, off, 64);
+				if(lane >= off) upto += below;
+			}
+			if(lane < COOP_HEAD_WORDS) sh.rank0[lane] = (uint16_t)(upto - mine);
+		}
+		wave_sync();
 		for(uint32_t base = 0; base < total; base += 64 * COOP_ITEMS) {
 			// COOP_ITEMS independent items per lane and trip, so their LDS and memory round trips overlap
 			uint32_t item[COOP_ITEMS], d[COOP_ITEMS];
 			#pragma unroll
-			for(int u = 0; u < COOP_ITEMS; u++) { item[u] = base + (uint32_t)(u * 64 + lane); d[u] = 0; }
-			for(uint32_t step = top; step >= 1; step >>= 1) {     // last descriptor that starts at or before the item
-				#pragma unroll
-				for(int u = 0; u < COOP_ITEMS; u++) {
-					uint32_t t = d[u] + step;
-					if(t < ndesc && (sh.desc_at[t] >> 12) <= item[u]) d[u] = t;
-				}
+			for(int u = 0; u < COOP_ITEMS; u++) {
+				item[u] = base + (uint32_t)(u * 64 + lane);
+				// a single list longer than the bitmap goes alone (ndesc == 1); positions past the end are not used
+				const uint32_t pos = (item[u] < total && item[u] < COOP_SEQ_MAX && ndesc > 1) ? item[u] : 0u;
+				const uint32_t heads = sh.head[pos >> 5] & (0xffffffffu >> (31u - (pos & 31u)));
+				d[u] = (uint32_t)sh.rank0[pos >> 5] + (uint32_t)__popc(heads) - 1u;
 			}
 			uint32_t who[COOP_ITEMS], id[COOP_ITEMS];
 			v4f e[COOP_ITEMS];
