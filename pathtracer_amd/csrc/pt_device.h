@@ -8,6 +8,7 @@
 
 #include "pt_api.h"
 #include "pt_launch.h"
+#include "pt_wavescan.h"
 
 #pragma clang fp contract(off)
 
@@ -601,7 +602,7 @@ constexpr int COOP_CELLS = PT_COOP_CELLS;               // cells a lane records 
 #define PT_COOP_POOL 256
 #endif
 #ifndef PT_COOP_DESCS
-#define PT_COOP_DESCS 336
+#define PT_COOP_DESCS 338
 #endif
 constexpr int COOP_POOL = PT_COOP_POOL;                 // candidates awaiting their intersection test
 constexpr int COOP_DESCS = PT_COOP_DESCS;               // non-empty cells the wavefront can note per segment
@@ -636,8 +637,6 @@ struct CoopShared {                           // one per wavefront
 	uint32_t sorted[COOP_POOL];               // the same, grouped by kind
 	uint32_t count[KIND_COUNT + 2];           // per kind, [KIND_COUNT] = total
 	uint32_t fill[KIND_COUNT + 2];
-	unsigned long long work;                  // descriptors noted << 32 | list entries they cover
-	unsigned long long cutoff;                // first descriptor turned away << 32 | its sequence position
 	uint32_t desc_k0[COOP_DESCS];             // first entry of the cell's list
 	uint32_t head[COOP_HEAD_WORDS];           // bit p set: a list starts at position p of the flattened sequence
 	uint16_t rank0[COOP_HEAD_WORDS];          // lists that start before the word's first position
@@ -673,6 +672,9 @@ PT_DEV void wave_sync() {
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+PT_DEV int lanes_under(uint64_t mask) {   // set bits of mask in lanes below this one
+	return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 PT_DEV uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 PT_DEV uint32_t pack_cell(int x, int y, int z) { return (uint32_t)x | ((uint32_t)y << 10) | ((uint32_t)z << 20); }
@@ -847,7 +849,6 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 		PT_TICK(t0);
 		// ---- reset the wavefront's bins --------------------------------------------------------
 		if(lane < KIND_COUNT + 2) { sh.count[lane] = 0; sh.fill[lane] = 0; }
-		if(lane == 0) { sh.work = 0; sh.cutoff = COOP_NONE; }
 		if(lane < COOP_HEAD_WORDS) sh.head[lane] = 0;
 		sh.best[lane] = COOP_NONE;
 		sh.ncell[lane] = 0;
@@ -866,49 +867,63 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 			probe.sx = sign_of(dir.x); probe.sy = sign_of(dir.y); probe.sz = sign_of(dir.z);
 			probe.dx = st.dx; probe.dy = st.dy; probe.dz = st.dz;
 		}
+		uint32_t cc[COOP_CELLS], ka[COOP_CELLS], kb[COOP_CELLS];
+		#pragma unroll
+		for(int j = 0; j < COOP_CELLS; j++) { cc[j] = 0; ka[j] = 0; kb[j] = 0; }
 		if(walking) {
 			int pc[COOP_CELLS];
-			uint32_t cc[COOP_CELLS], ka[COOP_CELLS], kb[COOP_CELLS];
 			#pragma unroll
 			for(int j = 0; j < COOP_CELLS; j++) {
-				pc[j] = 0; cc[j] = 0;
+				pc[j] = 0;
 				if(more) { pc[j] = lite_cell(sc.grid, probe); cc[j] = pack_cell(probe.cx, probe.cy, probe.cz); m = j + 1; more = lite_next(sc.grid, probe); }
 			}
 			#pragma unroll
 			for(int j = 0; j < COOP_CELLS; j++) { ka[j] = sc.cell_start[pc[j]]; kb[j] = sc.cell_start[pc[j] + 1]; }
-			// Descriptors are reserved cell by cell, all lanes in step, so that when they run out it is the
-			// far cells of every ray that wait for the next segment, not all cells of some rays.
-			uint32_t slot = 0, start = 0;
-			bool open = true;
-			#pragma unroll
-			for(int j = 0; j < COOP_CELLS; j++) {
-				if(j < m && open) {
-					uint32_t c = kb[j] - ka[j];
-					if(c > 0) {
-						{
-							unsigned long long old = atomicAdd(&sh.work, (1ull << 32) | (unsigned long long)c);
-							slot = (uint32_t)(old >> 32); start = (uint32_t)old;
-						}
-						if(slot >= (uint32_t)COOP_DESCS || (start > 0 && start + c > COOP_SEQ_MAX)) {
-							// no room left this segment: this cell and the ones after it wait for the next.  Slots
-							// and positions grow together, so everything reserved after the first refusal is refused too.
-							atomicMin(&sh.cutoff, ((unsigned long long)slot << 32) | (unsigned long long)start);
-							open = false;
-						} else {
-							sh.desc_k0[slot] = ka[j];
-							// the face the ray came in through, from the coordinate that changed: -x +x -y +y -z +z
-							uint32_t face = 7;
-							if(j > 0) {
-								const int step = (int)cc[j] - (int)cc[j > 0 ? j - 1 : 0];
-								face = step == 1 ? 0u : step == -1 ? 1u : step == 1024 ? 2u : step == -1024 ? 3u : step > 0 ? 4u : 5u;
-							}
-							sh.desc_at[slot] = (start << 12) | (uint32_t)lane | ((uint32_t)j << 6) | (face << 9);
-							atomicOr(&sh.head[start >> 5], 1u << (start & 31u));       // start < COOP_SEQ_MAX for every accepted list
-						}
+		}
+		// Descriptors and sequence positions are dealt cell by cell, all lanes in step (a wave prefix sum per
+		// step, in registers), so that when they run out it is the far cells of every ray that wait for the
+		// next segment, not all cells of some rays.  Slots and positions grow together, so everything after
+		// the first refusal is refused too.
+		uint32_t next_slot = 0, next_pos = 0;          // wave-uniform
+		bool cut = false;
+		uint32_t cut_slot = 0, cut_pos = 0;
+		bool open = walking;
+		#pragma unroll
+		for(int j = 0; j < COOP_CELLS; j++) {
+			const bool here = open && j < m;
+			const uint32_t c = here ? kb[j] - ka[j] : 0u;
+			const uint32_t upto = wave_inclusive_sum(c);
+			const uint64_t listed = __ballot(c > 0);
+			const uint32_t slot = next_slot + (uint32_t)lanes_under(listed);
+			const uint32_t start = next_pos + upto - c;
+			const bool refused = c > 0 && (cut || slot >= (uint32_t)COOP_DESCS || (start > 0 && start + c > COOP_SEQ_MAX));
+			const uint64_t turned_away = __ballot(refused);
+			if(turned_away != 0 && !cut) {
+				const int first = __ffsll((unsigned long long)turned_away) - 1;
+				cut = true;
+				cut_slot = (uint32_t)__builtin_amdgcn_readlane((int)slot, first);
+				cut_pos = (uint32_t)__builtin_amdgcn_readlane((int)start, first);
+			}
+			if(c > 0) {
+				if(refused) {
+					open = false;          // this cell and the ones after it wait for the next segment
+				} else {
+					sh.desc_k0[slot] = ka[j];
+					// the face the ray came in through, from the coordinate that changed: -x +x -y +y -z +z
+					uint32_t face = 7;
+					if(j > 0) {
+						const int step = (int)cc[j] - (int)cc[j > 0 ? j - 1 : 0];
+						face = step == 1 ? 0u : step == -1 ? 1u : step == 1024 ? 2u : step == -1024 ? 3u : step > 0 ? 4u : 5u;
 					}
-					if(open) { sh.cells[j][lane] = cc[j]; recorded = j + 1; }
+					sh.desc_at[slot] = (start << 12) | (uint32_t)lane | ((uint32_t)j << 6) | (face << 9);
+					atomicOr(&sh.head[start >> 5], 1u << (start & 31u));       // start < COOP_SEQ_MAX for every accepted list
 				}
 			}
+			if(here && open) { sh.cells[j][lane] = cc[j]; recorded = j + 1; }
+			next_slot += (uint32_t)__popcll(listed);
+			next_pos += (uint32_t)__builtin_amdgcn_readlane((int)upto, 63);
+		}
+		if(walking) {
 			sh.ncell[lane] = (uint8_t)recorded;
 			PT_STAT(4, recorded);
 		}
@@ -916,12 +931,8 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 		PT_TOCK(sh, 10, t0);
 
 		// ---- expand: the lists of all lanes as one sequence, 64 entries per round ------------------
-		const unsigned long long work = sh.work;
-		const uint32_t noted = uniform((uint32_t)(work >> 32));
-		const unsigned long long cutoff = sh.cutoff;
-		const uint32_t refused = uniform((uint32_t)(cutoff >> 32));
-		const uint32_t ndesc = noted < refused ? noted : refused;
-		const uint32_t total = uniform(cutoff != COOP_NONE ? (uint32_t)cutoff : (uint32_t)work);
+		const uint32_t ndesc = cut ? cut_slot : next_slot;
+		const uint32_t total = cut ? cut_pos : next_pos;
 		// Which list an entry position belongs to: descriptors are in position order, so it is the number of
 		// list heads at or before the position, less one - a prefix count per bitmap word plus a popcount.
 		{
