@@ -186,6 +186,11 @@ int pt_get_stats(const pt_ctx* ctx, pt_stats* stats);
  * the prepared scene.
  */
 int pt_debug_primary(pt_ctx* ctx, int32_t* hit_id, uint64_t* cell_hash);
+/* Diagnostic builds of the library only (-DPT_COOP_STATS / -DPT_COOP_TIMING): copies out and clears 16
+ * event or cycle counters of the trace kernel; returns 16, or 0 in a normal build (nothing written).
+ * No counterpart in the reference. */
+int pt_debug_coop_stats(pt_ctx* ctx, unsigned long long* counters16);
+
 /* Debug read-back of the uniform grid the prepared scene uses (the reference's per-cell ObjectLists,
  * code/app.cpp:1278-1354, in CSR form; built on the device for scenes of 4096 entities or more, on
  * the host otherwise; the environment variable PT_GRID_BUILD=host|device overrides the choice).
