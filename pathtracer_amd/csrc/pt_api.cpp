@@ -233,6 +233,17 @@ int prepare(pt_ctx* c) {
 		float* g0 = slot(0); g0[0] = r[PT_F_POS]; g0[1] = r[PT_F_POS + 1]; g0[2] = r[PT_F_POS + 2]; g0[3] = r[PT_F_BRADIUS];
 		memcpy(slot(1), r + PT_F_ROT, 16);
 		memcpy(slot(2), r + PT_F_ROTINV, 16);
+		if(type == PT_GEOM_BOX && !(flags & 1)) {
+			// an unrotated box never reads its rotation: the slots hold the corners lineBoxIntersection
+			// derives from position and size (code/raycast.cpp:420-426), in the same fp32 operations
+			float* lo = slot(1), *hi = slot(2);
+			for(int k = 0; k < 3; k++) {
+				const float half = r[PT_F_DIM + k] / 2;
+				lo[k] = r[PT_F_POS + k] - half;
+				hi[k] = r[PT_F_POS + k] + half;
+			}
+			lo[3] = 0; hi[3] = 0;
+		}
 		float* g3 = slot(3); g3[0] = r[PT_F_DIM]; g3[1] = r[PT_F_DIM + 1]; g3[2] = r[PT_F_DIM + 2]; g3[3] = tf_bits;
 		float* g4 = slot(4); g4[0] = r[PT_F_SCALE]; g4[1] = r[PT_F_SCALE + 1]; g4[2] = r[PT_F_SCALE + 2]; g4[3] = r[PT_F_ROUGH];
 		float* g5 = slot(5); g5[0] = r[PT_F_SCALEINV]; g5[1] = r[PT_F_SCALEINV + 1]; g5[2] = r[PT_F_SCALEINV + 2]; g5[3] = 0;

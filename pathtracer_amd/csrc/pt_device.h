@@ -116,6 +116,7 @@ PT_DEV uint32_t rng_bounded(Rng& r) {
 // touches one line, and a wave-uniform index turns into wide scalar loads): six geometry slots read
 // while intersecting and two material slots read once per hit.
 //   G0 pos.xyz | bounding-sphere radius     G1 rot (w,x,y,z)          G2 rotInverse (w,x,y,z)
+//      (an unrotated box keeps its corners pos - dim/2, pos + dim/2 in G1, G2 instead)
 //   G3 dim.xyz | type + flags<<8 (int bits) G4 dimScale.xyz | roughness   G5 dimScaleInverse.xyz | -
 //   M0 colorLinear.rgb | reflectionMod      M1 emitColorLinear.rgb | refractiveIndex
 enum { G_POS = 0, G_ROT = 1, G_ROTINV = 2, G_DIM = 3, G_SCALE = 4, G_SCALEINV = 5, M_COLOR = 6, M_EMIT = 7, G_SLOTS = 8 };
@@ -169,10 +170,8 @@ PT_DEV bool touches_sphere(V3 lp, V3 ld, V3 sp, float sr) {  // lineSphereCollis
 	return touches;
 }
 
-PT_DEV float hit_box(V3 lp, V3 ld, V3 bpos, V3 bdim, V3& pos, V3& nrm) {
-	V3 half = bdim / 2;
-	V3 bmin = bpos - half;
-	V3 bmax = bpos + half;
+// The slab test of lineBoxIntersection once the box's corners are known.
+PT_DEV float hit_slabs(V3 lp, V3 ld, V3 bmin, V3 bmax, V3& pos, V3& nrm) {
 	float fx = 1.0f / ld.x, fy = 1.0f / ld.y, fz = 1.0f / ld.z;
 	float t1 = (bmin.x - lp.x) * fx;
 	float t2 = (bmax.x - lp.x) * fx;
@@ -194,6 +193,10 @@ PT_DEV float hit_box(V3 lp, V3 ld, V3 bpos, V3 bdim, V3& pos, V3& nrm) {
 	else if(distance == t6) nrm = v3(0, 0, 1);
 	else nrm = v3(0, 0, 0);
 	return distance;
+}
+PT_DEV float hit_box(V3 lp, V3 ld, V3 bpos, V3 bdim, V3& pos, V3& nrm) {
+	V3 half = bdim / 2;
+	return hit_slabs(lp, ld, bpos - half, bpos + half, pos, nrm);
 }
 
 PT_DEV float hit_cylinder(V3 p, V3 d, V3& pos, V3& nrm) {
@@ -313,9 +316,12 @@ PT_DEV float intersect_kind(const GeoRef& g, v4f p0, v4f p3, V3 rp, V3 rd, V3& p
 	V3 dim = v3(p3.x, p3.y, p3.z);
 	float distance = -1;
 	if(KIND == KIND_SPHERE) {
-		distance = hit_sphere(rp, rd, opos, dim.x * 0.5f, pos, nrm);
+		// the bounding radius of a sphere with three equal dims is dim.x * 0.5f, the radius the reference passes
+		distance = hit_sphere(rp, rd, opos, p0.w, pos, nrm);
 	} else if(KIND == KIND_BOX) {
-		distance = hit_box(rp, rd, opos, dim, pos, nrm);
+		// corners of an unrotated box (pos -/+ dim / 2), kept by the host in the record's unused rotation slots
+		v4f lo = g.plane(G_ROT), hi = g.plane(G_ROTINV);
+		distance = hit_slabs(rp, rd, v3(lo.x, lo.y, lo.z), v3(hi.x, hi.y, hi.z), pos, nrm);
 	} else if(KIND == KIND_BOX_ROTATED) {
 		v4f ri = g.plane(G_ROTINV);
 		V3 lp = rp - opos;
@@ -354,8 +360,11 @@ constexpr int KIND_MIXED = KIND_COUNT;
 PT_DEV float intersect_mixed(int kind, const GeoRef& g, v4f p0, v4f p3, V3 rp, V3 rd, V3& pos, V3& nrm) {
 	V3 opos = v3(p0.x, p0.y, p0.z);
 	V3 dim = v3(p3.x, p3.y, p3.z);
-	if(kind == KIND_SPHERE) return hit_sphere(rp, rd, opos, dim.x * 0.5f, pos, nrm);
-	if(kind == KIND_BOX) return hit_box(rp, rd, opos, dim, pos, nrm);
+	if(kind == KIND_SPHERE) return hit_sphere(rp, rd, opos, p0.w, pos, nrm);
+	if(kind == KIND_BOX) {
+		v4f lo = g.plane(G_ROT), hi = g.plane(G_ROTINV);
+		return hit_slabs(rp, rd, v3(lo.x, lo.y, lo.z), v3(hi.x, hi.y, hi.z), pos, nrm);
+	}
 	const bool isbox = kind == KIND_BOX_ROTATED;
 	const bool turned = isbox || ((__float_as_int(p3.w) >> 8) & FLAG_ROTATED);
 	v4f si = g.plane(G_SCALEINV);
