@@ -624,7 +624,7 @@ constexpr int COOP_ITEMS = PT_COOP_ITEMS;                 // list entries a lane
 #define PT_COOP_HEAD_WORDS 32
 #endif
 constexpr int COOP_HEAD_WORDS = PT_COOP_HEAD_WORDS;       // words of the list-head bitmap (at most 64: one lane scans one word)
-constexpr uint32_t COOP_SEQ_MAX = 32u * COOP_HEAD_WORDS;  // list entries one segment can hold (a longer single list goes alone)
+constexpr uint32_t COOP_SEQ_MAX = 32u * COOP_HEAD_WORDS;  // positions a list may start at in one segment
 static_assert(PT_COOP_CELLS <= 8, "the cell ordinal has three bits in a descriptor");
 #ifndef PT_COOP_MIX_ALL
 #define PT_COOP_MIX_ALL 128
@@ -647,6 +647,7 @@ struct CoopShared {                           // one per wavefront
 	uint32_t count[KIND_COUNT + 2];           // per kind, [KIND_COUNT] = total
 	uint32_t fill[KIND_COUNT + 2];
 	uint32_t desc_k0[COOP_DESCS];             // first entry of the cell's list
+	uint32_t turn;                            // segments this wavefront has run: which lane is served first
 	uint32_t head[COOP_HEAD_WORDS];           // bit p set: a list starts at position p of the flattened sequence
 	uint16_t rank0[COOP_HEAD_WORDS];          // lists that start before the word's first position
 	uint32_t desc_at[COOP_DESCS];             // position of that entry in the flattened sequence << 12 |
@@ -859,6 +860,7 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 		// ---- reset the wavefront's bins --------------------------------------------------------
 		if(lane < KIND_COUNT + 2) { sh.count[lane] = 0; sh.fill[lane] = 0; }
 		if(lane < COOP_HEAD_WORDS) sh.head[lane] = 0;
+		if(lane == 0) sh.turn = sh.turn + 1u;
 		sh.best[lane] = COOP_NONE;
 		sh.ncell[lane] = 0;
 		wave_sync();
@@ -891,8 +893,12 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 		}
 		// Descriptors and sequence positions are dealt cell by cell, all lanes in step (a wave prefix sum per
 		// step, in registers), so that when they run out it is the far cells of every ray that wait for the
-		// next segment, not all cells of some rays.  Slots and positions grow together, so everything after
-		// the first refusal is refused too.
+		// next segment, not all cells of some rays.  Within a step the lanes are served in an order that starts
+		// one lane later every segment, so no lane is last for ever.  A list is taken while a descriptor is
+		// free and its first entry lies inside the bitmap; slots and positions grow together, so everything
+		// after the first refusal is refused too (a list may run past the bitmap's end: it is then the last).
+		const uint32_t rot = uniform(sh.turn) & 63u;
+		const uint64_t before_rot = rot ? (1ull << rot) - 1ull : 0ull;
 		uint32_t next_slot = 0, next_pos = 0;          // wave-uniform
 		bool cut = false;
 		uint32_t cut_slot = 0, cut_pos = 0;
@@ -902,13 +908,18 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 			const bool here = open && j < m;
 			const uint32_t c = here ? kb[j] - ka[j] : 0u;
 			const uint32_t upto = wave_inclusive_sum(c);
+			const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)upto, 63);
+			const uint32_t skipped = rot ? (uint32_t)__builtin_amdgcn_readlane((int)upto, (int)rot - 1) : 0u;   // entries of the lanes served last
 			const uint64_t listed = __ballot(c > 0);
-			const uint32_t slot = next_slot + (uint32_t)lanes_under(listed);
-			const uint32_t start = next_pos + upto - c;
-			const bool refused = c > 0 && (cut || slot >= (uint32_t)COOP_DESCS || (start > 0 && start + c > COOP_SEQ_MAX));
+			const uint32_t lists = (uint32_t)__popcll(listed), lists_skipped = (uint32_t)__popcll(listed & before_rot);
+			const bool early = (uint32_t)lane >= rot;
+			const uint32_t slot = next_slot + (uint32_t)lanes_under(listed) + (early ? 0u - lists_skipped : lists - lists_skipped);
+			const uint32_t start = next_pos + (upto - c) + (early ? 0u - skipped : all - skipped);
+			const bool refused = c > 0 && (cut || slot >= (uint32_t)COOP_DESCS || start >= COOP_SEQ_MAX);
 			const uint64_t turned_away = __ballot(refused);
 			if(turned_away != 0 && !cut) {
-				const int first = __ffsll((unsigned long long)turned_away) - 1;
+				const uint64_t in_order = rot ? (turned_away >> rot) | (turned_away << (64u - rot)) : turned_away;
+				const int first = (int)(((uint32_t)__ffsll((unsigned long long)in_order) - 1u + rot) & 63u);
 				cut = true;
 				cut_slot = (uint32_t)__builtin_amdgcn_readlane((int)slot, first);
 				cut_pos = (uint32_t)__builtin_amdgcn_readlane((int)start, first);
@@ -925,12 +936,12 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 						face = step == 1 ? 0u : step == -1 ? 1u : step == 1024 ? 2u : step == -1024 ? 3u : step > 0 ? 4u : 5u;
 					}
 					sh.desc_at[slot] = (start << 12) | (uint32_t)lane | ((uint32_t)j << 6) | (face << 9);
-					atomicOr(&sh.head[start >> 5], 1u << (start & 31u));       // start < COOP_SEQ_MAX for every accepted list
+					atomicOr(&sh.head[start >> 5], 1u << (start & 31u));       // start < COOP_SEQ_MAX for every list taken
 				}
 			}
 			if(here && open) { sh.cells[j][lane] = cc[j]; recorded = j + 1; }
-			next_slot += (uint32_t)__popcll(listed);
-			next_pos += (uint32_t)__builtin_amdgcn_readlane((int)upto, 63);
+			next_slot += lists;
+			next_pos += all;
 		}
 		if(walking) {
 			sh.ncell[lane] = (uint8_t)recorded;
@@ -960,10 +971,11 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 			#pragma unroll
 			for(int u = 0; u < COOP_ITEMS; u++) {
 				item[u] = base + (uint32_t)(u * 64 + lane);
-				// a single list longer than the bitmap goes alone (ndesc == 1); positions past the end are not used
-				const uint32_t pos = (item[u] < total && item[u] < COOP_SEQ_MAX && ndesc > 1) ? item[u] : 0u;
+				// positions past the bitmap's end belong to the last list; positions past the sequence's end are not used
+				const bool past = item[u] >= COOP_SEQ_MAX;
+				const uint32_t pos = (item[u] < total && !past) ? item[u] : 0u;
 				const uint32_t heads = sh.head[pos >> 5] & (0xffffffffu >> (31u - (pos & 31u)));
-				d[u] = (uint32_t)sh.rank0[pos >> 5] + (uint32_t)__popc(heads) - 1u;
+				d[u] = (past && item[u] < total) ? ndesc - 1u : (uint32_t)sh.rank0[pos >> 5] + (uint32_t)__popc(heads) - 1u;
 			}
 			uint32_t who[COOP_ITEMS], id[COOP_ITEMS];
 			v4f e[COOP_ITEMS];

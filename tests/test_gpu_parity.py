@@ -414,6 +414,30 @@ def test_small_and_ragged_images(gpu, w, h, spp):
     assert (bits(img) == bits(ref)).all()
 
 
+def test_device_grid_build_hands_long_lists_to_the_host(gpu, monkeypatch):
+    """The device build sorts a cell's list with one thread, so a cell that lists more than 4096 entities
+    sends the build back to the host; the render is the oracle's either way."""
+    rng = np.random.default_rng(3)
+    world, base = scenes.default_scene()
+    objs = [base[0]]
+    for _ in range(5000):                                   # 5000 small spheres inside one grid cell
+        p = rng.uniform(-0.3, 0.3, 3) + np.array([3.0, 3.0, 6.5])
+        objs.append(make_object(tuple(float(v) for v in p), (0.05, 0.05, 0.05), api.PT_GEOM_SPHERE, color=(0.8, 0.3, 0.3)))
+    st = default_settings(48, 27, 2, 3, seed=9, grid_hint=4)
+    monkeypatch.setenv("PT_GRID_BUILD", "device")
+    img = gpu.render(world, objs, st)
+    start, lists, _, on_device = gpu.debug_grid()
+    monkeypatch.delenv("PT_GRID_BUILD")
+    assert not on_device and int(np.diff(start).max()) > 4096
+    sc = OracleScene(world, objs, st)
+    ref = np.zeros((27, 48, 3), np.float32)
+    sc.lib.pto_render_rect(sc.h, 0, 3, 0, 0, 48, 27, P(ref))
+    _, cs, ci = sc.grid()
+    sc.close()
+    assert (cs == start).all() and (ci == lists).all()
+    assert (bits(img) == bits(ref)).all()
+
+
 def test_zero_sample_tile_is_black(gpu):
     world, objs = scenes.default_scene()
     for seed in range(40):
