@@ -74,6 +74,16 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 	if((int)threadIdx.x <= tile_w * tile_w) bucket[threadIdx.x] = sc.offsets[threadIdx.x];
 	__syncthreads();
 	const int mod_magic = 65536 / tile_w + 1;   // v % tile_w for v < 16 and tile_w <= 4 without a division
+	// Staged hand-out (every variant but the cooperative cast, whose LDS share is full): the wave that fetches a
+	// group works out its 64 items with all lanes at once and parks them in LDS, 32 bytes each, so that a lane in
+	// need of work only reads its item instead of the whole wave stepping through the per-pixel arithmetic for it.
+	//   a: first sample's table index | si + (si_end << 16) | lens-table start | progressive pass
+	//   b: pixel centre on the image plane (x y z) | pixel slot
+	constexpr bool kStaged = MODE != CAST_GRID_COOP;
+	__shared__ uint4 staged[kStaged ? 2 * kBlock : 1];
+	uint4* const stage_a = staged + (kStaged ? (threadIdx.x / 64) * 128 : 0);
+	uint4* const stage_b = stage_a + (kStaged ? 64 : 0);
+	size_t tile_item0 = 0;                     // first range sum of the staged group's range
 	bool dry = false;
 	uint32_t shard = blockIdx.x % kShards;     // lane 0's view is the one that counts
 
@@ -140,10 +150,56 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 				tile_mx = tile_x0 % tile_w;
 				tile_my = tile_y0 % tile_w;
 				pool_pos = 0;
+				if(kStaged) {
+					tile_item0 = (size_t)tile_range * job.slots;
+					const int j = lane, x = tile_x0 + (j & 7), y = tile_y0 + (j >> 3);
+					uint4 a = make_uint4(0u, 0u, 0u, 0u), b = make_uint4(0u, 0u, 0u, 0u);
+					if(x < width && y < height) {
+						const uint32_t slot = job.compact ? (uint32_t)(tile_slot0 + j) : (uint32_t)y * (uint32_t)width + (uint32_t)x;
+						const int vx = tile_mx + (j & 7), vy = tile_my + (j >> 3);
+						const int rx = vx - ((vx * mod_magic) >> 16) * tile_w, ry = vy - ((vy * mod_magic) >> 16) * tile_w;
+						const int t = ry * tile_w + rx;                // (y % tile_w) * tile_w + (x % tile_w)
+						const int first = bucket[t], n_samples = bucket[t + 1] - first;
+						int s0 = 0, s1 = 0;
+						uint32_t round = 0;
+						if(job.frame_index < 0) {
+							s0 = (tile_range * n_samples) >> ranges_log2;
+							s1 = ((tile_range + 1) * n_samples) >> ranges_log2;
+						} else if(n_samples > 0) {
+							s0 = job.frame_index % n_samples; s1 = s0 + 1; round = (uint32_t)(job.frame_index / n_samples);
+						}
+						if(s0 == s1) {
+							// nothing to trace (a bucket without samples, code/raycast.cpp:1270, or fewer samples than ranges)
+							job.partial[tile_item0 + slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(job.serial));
+						} else {
+							const V3 o = pixel_origin_tab(job, fr, x, y);
+							a = make_uint4((uint32_t)first, (uint32_t)s0 | ((uint32_t)s1 << 16), fr->aperture != 0.0f ? (uint32_t)lens_start(fr, x, y) : 0u, round);
+							b = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), slot);
+						}
+					}
+					stage_a[lane] = a;
+					stage_b[lane] = b;
+					wave_sync();
+				}
 			}
 			int avail = kGroup - pool_pos;
 			int rank = lanes_below(want);
-			if(state == NEED_PIXEL && rank < avail) {
+			if(kStaged) {
+				if(state == NEED_PIXEL && rank < avail) {
+					const int j = pool_pos + rank;
+					const uint4 a = stage_a[j];
+					if(a.y != 0u) {                                  // else: outside the image or nothing to trace - the lane asks again
+						const uint4 b = stage_b[j];
+						px = tile_x0 + (j & 7);
+						py = tile_y0 + (j >> 3);
+						sample_base = (int)a.x; si = (int)(a.y & 0xffffu); si_end = (int)(a.y >> 16); lens = (int)a.z; pass = a.w;
+						origin = v3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+						item = tile_item0 + b.w;
+						sum = v3(0, 0, 0);
+						state = NEED_PATH;
+					}
+				}
+			} else if(state == NEED_PIXEL && rank < avail) {
 				const int j = pool_pos + rank;
 				px = tile_x0 + (j & 7);
 				py = tile_y0 + (j >> 3);

@@ -2,7 +2,7 @@
 # builds pathtracer_amd/variant_<name>.so with extra compiler flags (A/B timing of kernel variants)
 # usage: profiles/build_variant.sh <name> [extra hipcc flags...]
 name=$1; shift
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt "$@" \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize "$@" \
 	-Iinclude -Ipathtracer_amd/csrc pathtracer_amd/csrc/pt_api.cpp pathtracer_amd/csrc/pt_host.cpp pathtracer_amd/csrc/pt_scene.cpp pathtracer_amd/csrc/pt_kernels.hip pathtracer_amd/csrc/pt_gridbuild.hip \
 	-o pathtracer_amd/variant_$name.so -Rpass-analysis=kernel-resource-usage > /tmp/variant_$name.log 2>&1
 rc=$?
