@@ -205,6 +205,16 @@ int pt_debug_grid(pt_ctx* ctx, uint32_t* cell_start, int cell_capacity, uint32_t
 int pt_cast_rays(pt_ctx* ctx, const float* origins, const float* dirs, int n,
                  int32_t* hit_id, float* hit_pos, float* hit_normal);
 
+/* Arithmetic probes, for tests.  The device computes the reference's divisions and square roots
+ * (normVec3 code/rt_math.cpp:2166-2168, lenVec3 :2130-2164, Vec3 / float :2093) with shorter instruction
+ * sequences than the compiler's whenever the operands allow it; every result must still be the IEEE
+ * one.  op 0: out[i] = sqrt(a[i]); op 1: out[3i..] = a[3i..] / b[i]; op 2: out[3i..] = a[3i..] /
+ * length(a[3i..]); op 3: out[3i..] = a[3i..] / (float)pi.  Host pointers.  pt_debug_arith_sweep runs
+ * `count` (at most 2^32) consecutive bit patterns from first_bits through the same op on the device,
+ * with derived companions, and counts results whose bits differ from the compiler's own sequences. */
+int pt_debug_arith(pt_ctx* ctx, int op, const float* a, const float* b, int n, float* out);
+int pt_debug_arith_sweep(pt_ctx* ctx, int op, uint32_t first_bits, uint64_t count, uint64_t* mismatches);
+
 /* Screenshot stage code/app.cpp:1536-1552: linear float -> sRGB OETF -> 8-bit, on the device
  * framebuffer of the last trace. rgb8 holds width*height*3 bytes. */
 int pt_present_srgb8(pt_ctx* ctx, uint8_t* rgb8);

@@ -159,6 +159,8 @@ def load_core():
     lib.pt_cast_rays.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
                                  C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.pt_present_srgb8.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
+    lib.pt_debug_arith.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float)]
+    lib.pt_debug_arith_sweep.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.pt_default_scene.argtypes = [C.POINTER(pt_world), C.POINTER(pt_object), C.c_int, C.POINTER(C.c_int)]
     lib.pt_default_settings.argtypes = [C.POINTER(pt_settings)]
     lib.pt_host_flatten.argtypes = [C.POINTER(pt_object), C.c_int, C.POINTER(C.c_float)]
@@ -297,6 +299,20 @@ class Renderer:
         nrm = np.zeros((n, 3), np.float32)
         self._check(self.lib.pt_cast_rays(self.ctx, fptr(o), fptr(d), n, iptr(ids), fptr(pos), fptr(nrm)), "pt_cast_rays")
         return ids, pos, nrm
+
+    def arith(self, op, a, b=None):
+        """Device arithmetic probe: op 0 sqrt(a), 1 a[i, :] / b[i], 2 a[i, :] / |a[i, :]|, 3 a[i, :] / pi."""
+        a = np.ascontiguousarray(a, np.float32)
+        n = a.shape[0]
+        out = np.zeros_like(a)
+        bb = fptr(np.ascontiguousarray(b, np.float32)) if b is not None else None
+        self._check(self.lib.pt_debug_arith(self.ctx, op, fptr(a), bb, n, fptr(out)), "pt_debug_arith")
+        return out
+
+    def arith_sweep(self, op, first_bits, count):
+        bad = C.c_uint64(0)
+        self._check(self.lib.pt_debug_arith_sweep(self.ctx, op, first_bits, count, C.byref(bad)), "pt_debug_arith_sweep")
+        return bad.value
 
     def present_srgb8(self):
         s = self.settings

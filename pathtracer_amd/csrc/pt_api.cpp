@@ -771,6 +771,35 @@ int pt_cast_rays(pt_ctx* c, const float* origins, const float* dirs, int n, int3
 	return PT_OK;
 }
 
+int pt_debug_arith(pt_ctx* c, int op, const float* a, const float* b, int n, float* out) {
+	if(!c) return PT_ERR_ARG;
+	if(op < 0 || op > 3 || n < 0 || (n > 0 && (!a || !out || (op == 1 && !b)))) return fail(c, PT_ERR_ARG, "bad argument");
+	if(n == 0) return PT_OK;
+	PT_HIP(c, hipSetDevice(c->device));
+	const size_t per = op == 0 ? 1 : 3, va = (size_t)n * per * 4, vb = (size_t)n * 4;
+	PT_HIP(c, c->scratch.reserve(2 * va + vb + 1024));
+	char* base = (char*)c->scratch.p;
+	float* d_a = (float*)base; float* d_o = (float*)(base + va); float* d_b = (float*)(base + 2 * va);
+	PT_HIP(c, hipMemcpyAsync(d_a, a, va, hipMemcpyHostToDevice, c->stream));
+	if(op == 1) PT_HIP(c, hipMemcpyAsync(d_b, b, vb, hipMemcpyHostToDevice, c->stream));
+	PT_HIP(c, ptl::launch_arith(op, d_a, d_b, n, d_o, c->stream));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	PT_HIP(c, hipMemcpy(out, d_o, va, hipMemcpyDeviceToHost));
+	return PT_OK;
+}
+
+int pt_debug_arith_sweep(pt_ctx* c, int op, uint32_t first_bits, uint64_t count, uint64_t* mismatches) {
+	if(!c) return PT_ERR_ARG;
+	if(op < 0 || op > 3 || !mismatches || count > (1ull << 32)) return fail(c, PT_ERR_ARG, "bad argument");
+	PT_HIP(c, hipSetDevice(c->device));
+	PT_HIP(c, c->scratch.reserve(1024));
+	PT_HIP(c, hipMemsetAsync(c->scratch.p, 0, 8, c->stream));
+	PT_HIP(c, ptl::launch_arith_sweep(op, first_bits, count, (unsigned long long*)c->scratch.p, c->stream));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	PT_HIP(c, hipMemcpy(mismatches, c->scratch.p, 8, hipMemcpyDeviceToHost));
+	return PT_OK;
+}
+
 int pt_present_srgb8(pt_ctx* c, uint8_t* rgb8) {
 	if(!c) return PT_ERR_ARG;
 	if(!c->prepared) return fail(c, PT_ERR_STATE, "pt_present_srgb8 before pt_prepare");

@@ -55,12 +55,73 @@ PT_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
 PT_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
 PT_DEV V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
 PT_DEV V3 operator*(V3 a, float b) { return v3(a.x * b, a.y * b, a.z * b); }
-PT_DEV V3 operator/(V3 a, float b) { return v3(a.x / b, a.y / b, a.z / b); }
 PT_DEV V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
 PT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 PT_DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-PT_DEV float length(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
-PT_DEV V3 normalise(V3 a) { return a / length(a); }          // divides, never multiplies by a reciprocal
+
+// ---- correctly rounded division and square root, the short way ---------------------------------------
+// Every quotient and root has to be the IEEE result, bit for bit.  The compiler's a / b is eleven
+// instructions: both operands scaled (v_div_scale), v_rcp and one Newton step on the denominator, the
+// quotient with two residual corrections (five multiply-adds), the scaling undone (v_div_fmas) and the
+// special cases patched (v_div_fixup); its sqrtf is sixteen, seven of them scaling and special cases.
+// For operands of ordinary magnitude (non-zero, finite, far from the ends of the exponent range) the
+// scaling is by one and the fix-up passes its input through, so the arithmetic in between alone gives
+// the same bits; and quotients with a common denominator can then share its reciprocal, which the
+// compiler's form cannot (its scaling depends on each numerator).  The functions below run that core
+// for every lane and redo the compiler's full sequence for the lanes whose operands are not ordinary
+// (a branch the wavefront skips when there are none).
+constexpr float kPlainLo = 0x1p-40f, kPlainHi = 0x1p40f;      // magnitudes the short forms accept
+PT_DEV float min3abs(V3 a) { return __builtin_fminf(__builtin_fminf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z)); }
+// An upper bound of the three magnitudes that is NaN when any of them is (a three-operand maximum drops
+// NaNs, and after a signalling one it can drop a second operand with it).
+PT_DEV float sum3abs(V3 a) { return (__builtin_fabsf(a.x) + __builtin_fabsf(a.y)) + __builtin_fabsf(a.z); }
+PT_DEV float recip_near(float b) {                   // v_rcp and one Newton step
+	const float r = __builtin_amdgcn_rcpf(b);
+	const float e = __builtin_fmaf(-b, r, 1.0f);
+	return __builtin_fmaf(e, r, r);
+}
+PT_DEV float quotient(float a, float b, float r) {   // a / b given r = recip_near(b), ordinary operands
+	float q = a * r;
+	float e = __builtin_fmaf(-b, q, a);
+	q = __builtin_fmaf(e, r, q);
+	e = __builtin_fmaf(-b, q, a);
+	return __builtin_fmaf(e, r, q);
+}
+PT_DEV float root_core(float x) {                    // sqrt of an ordinary x: v_sqrt, then the neighbour whose residual fits
+	const float s = __builtin_amdgcn_sqrtf(x);
+	const float down = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+	const float r_down = __builtin_fmaf(-down, s, x), r_up = __builtin_fmaf(-up, s, x);
+	float t = r_down <= 0.0f ? down : s;
+	t = r_up > 0.0f ? up : t;
+	return t;
+}
+PT_DEV float sq_root(float x) {
+	float s = root_core(x);
+	if(!(x >= 0x1p-90f && x <= 0x1p100f)) s = sqrtf(x);
+	return s;
+}
+// Three quotients with one denominator.
+PT_DEV V3 operator/(V3 a, float b) {
+	const float r = recip_near(b);
+	V3 q = v3(quotient(a.x, b, r), quotient(a.y, b, r), quotient(a.z, b, r));
+	const float m = __builtin_fabsf(b);
+	if(!(min3abs(a) >= kPlainLo && sum3abs(a) <= kPlainHi && m >= kPlainLo && m <= kPlainHi)) q = v3(a.x / b, a.y / b, a.z / b);
+	return q;
+}
+PT_DEV float length(V3 a) { return sq_root(a.x * a.x + a.y * a.y + a.z * a.z); }
+// a / length(a): divides, never multiplies by a reciprocal (code/rt_math.cpp:2166-2168).  Components of at
+// least 2^-40 and a sum of squares of at most 2^80 make the root and all three quotients ordinary.
+PT_DEV V3 normalise(V3 a) {
+	const float ss = a.x * a.x + a.y * a.y + a.z * a.z;
+	float l = root_core(ss);
+	const float r = recip_near(l);
+	V3 q = v3(quotient(a.x, l, r), quotient(a.y, l, r), quotient(a.z, l, r));
+	if(!(min3abs(a) >= kPlainLo && ss <= 0x1p80f)) {
+		l = sqrtf(ss);
+		q = v3(a.x / l, a.y / l, a.z / l);
+	}
+	return q;
+}
 PT_DEV bool is_zero(V3 a) { return a.x == 0 && a.y == 0 && a.z == 0; }
 // The reference's min/max are ternaries (code/rt_math.cpp:60-74); they differ from fminf/fmaxf on NaN.
 PT_DEV float tmin(float a, float b) { return a <= b ? a : b; }
@@ -134,7 +195,7 @@ PT_DEV float hit_sphere(V3 lp, V3 ld, V3 sp, float sr, V3& pos, V3& nrm) {
 	float b = d * d - l * l + sr * sr;
 	if(b < 0) return -1;
 	float distance = -(dot(ld, lp));
-	float sq = sqrtf(b);
+	float sq = sq_root(b);
 	if(distance - sq < 0) {
 		if(distance + sq < 0) return -1;
 		else distance += sq;
@@ -195,7 +256,7 @@ PT_DEV float hit_slabs(V3 lp, V3 ld, V3 bmin, V3 bmax, V3& pos, V3& nrm) {
 	return distance;
 }
 PT_DEV float hit_box(V3 lp, V3 ld, V3 bpos, V3 bdim, V3& pos, V3& nrm) {
-	V3 half = bdim / 2;
+	V3 half = bdim * 0.5f;            // the same floats as bdim / 2
 	return hit_slabs(lp, ld, bpos - half, bpos + half, pos, nrm);
 }
 
@@ -205,7 +266,7 @@ PT_DEV float hit_cylinder(V3 p, V3 d, V3& pos, V3& nrm) {
 	float c = (p.x * p.x + p.y * p.y) - 1;
 	float disc = b * b - 4 * a * c;
 	if(disc < 0) return -1;
-	float root = sqrtf(disc);
+	float root = sq_root(disc);
 	float t1 = (-b + root) / (2 * a);
 	float t2 = (-b - root) / (2 * a);
 	float z1 = p.z + d.z * t1;
@@ -237,7 +298,7 @@ PT_DEV float hit_cone(V3 p, V3 d, V3& pos, V3& nrm) {
 	float c = p.x * p.x + p.y * p.y - p.z * p.z;
 	float disc = b * b - 4 * a * c;
 	if(disc < 0) return -1;
-	float root = sqrtf(disc);
+	float root = sq_root(disc);
 	float t1 = (-b + root) / (2 * a);
 	float t2 = (-b - root) / (2 * a);
 	float z1 = p.z + d.z * t1;
@@ -436,7 +497,7 @@ PT_DEV bool grid_entry(const Grid& g, V3 rp, V3 rd, V3& p) {
 	p = rp;
 	if(!inside_box(rp, bmin, bmax)) {
 		V3 bdim = bmax - bmin;
-		V3 bpos = bmin + bdim / 2;
+		V3 bpos = bmin + bdim * 0.5f;     // the same floats as bdim / 2
 		V3 ip, in;
 		float distance = hit_box(rp, rd, bpos, bdim, ip, in);
 		if(distance != -1) p = ip + rd * 0.0001f;
@@ -1061,15 +1122,15 @@ PT_DEV V3 refract_dir(V3 incident, V3 normal, float ior) {
 	float eta = etai / etat;
 	float k = 1 - eta * eta * (1 - cosi * cosi);
 	if(k < 0) return v3(0, 0, 0);
-	return incident * eta + n * (eta * cosi - sqrtf(k));
+	return incident * eta + n * (eta * cosi - sq_root(k));
 }
 PT_DEV float fresnel(V3 incident, V3 normal, float ior) {
 	float cosi = cap_one(dot(incident, normal));
 	float etai = 1, etat = ior;
 	if(cosi > 0) { float t = etai; etai = etat; etat = t; }
-	float sint = etai / etat * sqrtf(tmax(0.0f, 1 - cosi * cosi));
+	float sint = etai / etat * sq_root(tmax(0.0f, 1 - cosi * cosi));
 	if(sint >= 1) return 1;
-	float cost = sqrtf(tmax(0.0f, 1 - sint * sint));
+	float cost = sq_root(tmax(0.0f, 1 - sint * sint));
 	cosi = fabsf(cosi);
 	float rs = ((etat * cosi) - (etai * cost)) / ((etat * cosi) + (etai * cost));
 	float rp = ((etai * cosi) - (etat * cost)) / ((etai * cosi) + (etat * cost));

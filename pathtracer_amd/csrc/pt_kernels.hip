@@ -440,6 +440,53 @@ __global__ __launch_bounds__(kBlock) void pt_k_cast(ptl::SceneDev scene, const f
 	if(hit_nrm) { hit_nrm[3 * i] = hn.x; hit_nrm[3 * i + 1] = hn.y; hit_nrm[3 * i + 2] = hn.z; }
 }
 
+// Arithmetic probes: the short forms of division and square root (pt_device.h) on caller-supplied operands,
+// and sweeps that compare them on the device with the compiler's own a / b and sqrtf over ranges of bit patterns.
+enum { ARITH_ROOT = 0, ARITH_OVER = 1, ARITH_NORMALISE = 2, ARITH_OVER_PI = 3 };
+__global__ __launch_bounds__(kBlock) void pt_k_arith(int op, const float* a, const float* b, int n, float* out) {
+	const int i = blockIdx.x * kBlock + threadIdx.x;
+	if(i >= n) return;
+	if(op == ARITH_ROOT) { out[i] = sq_root(a[i]); return; }
+	const V3 v = v3(a[3 * i], a[3 * i + 1], a[3 * i + 2]);
+	V3 q;
+	if(op == ARITH_OVER) q = v / b[i];
+	else if(op == ARITH_NORMALISE) q = normalise(v);
+	else q = v / 3.14159274101257324f;
+	out[3 * i] = q.x; out[3 * i + 1] = q.y; out[3 * i + 2] = q.z;
+}
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {     // a bijective scrambler: related operands from one counter
+	x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+	return x;
+}
+__device__ __forceinline__ bool same_bits(float p, float q) { return __float_as_uint(p) == __float_as_uint(q) || (p != p && q != q); }
+// The long forms, kept from being folded into the short ones: plain C division and sqrtf.
+__device__ __noinline__ float long_div(float a, float b) { return a / b; }
+__device__ __noinline__ float long_sqrt(float x) { return sqrtf(x); }
+__global__ __launch_bounds__(kBlock) void pt_k_arith_sweep(int op, uint32_t first, unsigned long long count, unsigned long long* mismatches) {
+	unsigned long long bad = 0;
+	for(unsigned long long k = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; k < count; k += (unsigned long long)gridDim.x * kBlock) {
+		const uint32_t bits = first + (uint32_t)k;
+		const float x = __uint_as_float(bits);
+		if(op == ARITH_ROOT) {
+			bad += same_bits(sq_root(x), long_sqrt(x)) ? 0 : 1;
+		} else {
+			// every bit pattern in x; y and z (and the denominator) of related or of unrelated magnitude, by turns
+			const uint32_t h = mix32(bits), g = mix32(bits ^ 0x9e3779b9u);
+			const bool near = (h >> 31) != 0;
+			const float y = near ? x * (0.001f + (float)(h & 0xffffu) * (1.0f / 256.0f)) : __uint_as_float(g);
+			const float z = near ? x * -(0.5f + (float)((h >> 16) & 0x7fffu) * (1.0f / 64.0f)) : __uint_as_float(mix32(g));
+			const V3 v = v3(x, y, z);
+			V3 q, w;
+			if(op == ARITH_OVER) { const float d = near ? x * (float)(1 + (g & 255u)) * 0.37f : __uint_as_float(mix32(h)); q = v / d; w = v3(long_div(x, d), long_div(y, d), long_div(z, d)); }
+			else if(op == ARITH_NORMALISE) { q = normalise(v); const float l = long_sqrt(x * x + y * y + z * z); w = v3(long_div(x, l), long_div(y, l), long_div(z, l)); }
+			else { const float pi = 3.14159274101257324f; q = v / pi; w = v3(long_div(x, pi), long_div(y, pi), long_div(z, pi)); }
+			bad += (same_bits(q.x, w.x) && same_bits(q.y, w.y) && same_bits(q.z, w.z)) ? 0 : 1;
+		}
+	}
+	for(int off = 32; off > 0; off >>= 1) bad += __shfl_down(bad, off, 64);
+	if(lane_id() == 0 && bad) atomicAdd(mismatches, bad);
+}
+
 // Screenshot encoding (code/app.cpp:1541-1547, code/rt_math.cpp:351-353,3634-3640).
 __global__ __launch_bounds__(kBlock) void pt_k_srgb8(const float* rgb, size_t n, uint8_t* out) {
 	size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -539,6 +586,20 @@ hipError_t launch_cast(const SceneDev& sc, const float* origins, const float* di
                        float* hit_nrm, hipStream_t stream) {
 	if(n <= 0) return hipSuccess;
 	hipLaunchKernelGGL(pt_k_cast, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, sc, origins, dirs, n, hit_id, hit_pos, hit_nrm);
+	return hipGetLastError();
+}
+
+hipError_t launch_arith(int op, const float* a, const float* b, int n, float* out, hipStream_t stream) {
+	if(n <= 0) return hipSuccess;
+	hipLaunchKernelGGL(pt_k_arith, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, op, a, b, n, out);
+	return hipGetLastError();
+}
+
+hipError_t launch_arith_sweep(int op, uint32_t first, unsigned long long count, unsigned long long* mismatches, hipStream_t stream) {
+	if(count == 0) return hipSuccess;
+	unsigned long long blocks = (count + kBlock - 1) / kBlock;
+	if(blocks > 8192) blocks = 8192;
+	hipLaunchKernelGGL(pt_k_arith_sweep, dim3((unsigned)blocks), dim3(kBlock), 0, stream, op, first, count, mismatches);
 	return hipGetLastError();
 }
 

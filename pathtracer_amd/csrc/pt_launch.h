@@ -66,6 +66,11 @@ hipError_t launch_tile_cost(const TraceJob& job, int local_tiles, uint16_t* cost
 hipError_t launch_primary_aov(const SceneDev& sc, const FrameDev* fr, int width, int height, int32_t* hit_id, uint64_t* cell_hash, hipStream_t stream);
 hipError_t launch_cast(const SceneDev& sc, const float* origins, const float* dirs, int n, int32_t* hit_id,
                        float* hit_pos, float* hit_nrm, hipStream_t stream);
+// Arithmetic probes of the short division / square-root forms: op 0 root(a[i]), 1 a[3i..] / b[i], 2 normalise(a[3i..]),
+// 3 a[3i..] / pi; the sweep counts, over `count` consecutive bit patterns from `first`, results that differ from the
+// compiler's own division and sqrtf.
+hipError_t launch_arith(int op, const float* a, const float* b, int n, float* out, hipStream_t stream);
+hipError_t launch_arith_sweep(int op, uint32_t first, unsigned long long count, unsigned long long* mismatches, hipStream_t stream);
 hipError_t launch_srgb8(const float* rgb, size_t n, uint8_t* out, hipStream_t stream);
 // Tile-major partition buffers (part_count of them, each `stride` floats apart) -> row-major image.
 hipError_t launch_assemble(const float* parts, size_t stride, int part_count, int width, int height, float* rgb, hipStream_t stream);

@@ -522,3 +522,62 @@ def test_argument_errors(gpu):
     st = default_settings(32, 18, 4, 2)
     img = gpu.render(world, [], st)
     assert (img == 1.0).all()
+
+
+# ---- the short division / square-root forms against IEEE arithmetic ------------------------------------
+def _arith_operands(n, seed):
+    """Triples and denominators of every kind: ordinary magnitudes, exact zeros of both signs, denormals,
+    huge and tiny values, infinities and NaNs, so that both the short forms and their fall-backs run."""
+    rng = np.random.default_rng(seed)
+    a = (rng.standard_normal((n, 3)) * np.exp(rng.uniform(-12, 12, (n, 1)))).astype(np.float32)
+    raw = rng.integers(0, 2**32, (n, 3), dtype=np.uint64).astype(np.uint32).view(np.float32)      # any bit pattern
+    a[n // 2:] = raw[n // 2:]
+    special = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-38, 3e38, -3e38, np.inf, -np.inf, np.nan, 1.0, -1.0, 1e-30, 1e30, 2.0**-40, 2.0**40], np.float32)
+    pick = rng.integers(0, special.size, (n, 3))
+    mask = rng.random((n, 3)) < 0.08
+    a[mask] = special[pick[mask]]
+    b = (rng.standard_normal(n) * np.exp(rng.uniform(-12, 12, n))).astype(np.float32)
+    b[::7] = raw[::7, 0]
+    b[::11] = special[pick[::11, 0]]
+    return a, b
+
+
+def _same(x, y):
+    return (bits(x) == bits(y)) | (np.isnan(x) & np.isnan(y))
+
+
+def _assert_same(got, want, what, *operands):
+    ok = _same(got, want)
+    if ok.all():
+        return
+    rows = np.unique(np.argwhere(~ok)[:, 0])[:6]
+    lines = [f"{what}: {(~ok).sum()} of {ok.size} results differ"]
+    for r in rows:
+        lines.append("  operands " + " | ".join(str(bits(o[r]).tolist() if np.ndim(o[r]) else hex(int(bits(o[r])))) + " " + str(o[r]) for o in operands)
+                     + f" -> got {got[r]} {bits(got[r]).tolist() if np.ndim(got[r]) else hex(int(bits(got[r])))} want {want[r]} {bits(want[r]).tolist() if np.ndim(want[r]) else hex(int(bits(want[r])))}")
+    raise AssertionError("\n".join(lines))
+
+
+def test_short_division_and_root_are_ieee(gpu):
+    n = 400000
+    a, b = _arith_operands(n, 5)
+    with np.errstate(all="ignore"):
+        # numpy's float32 divide and sqrt are the correctly rounded IEEE operations, as the CPU path's are
+        got = gpu.arith(1, a, b)
+        _assert_same(got, a / b[:, None], "Vec3 / float against IEEE division", a, b)
+        got = gpu.arith(3, a)
+        _assert_same(got, a / np.float32(3.14159274101257324), "Vec3 / pi against IEEE division", a)
+        x = np.abs(a[:, 0])
+        x[::5] = a[::5, 1]                                   # negative arguments too
+        got = gpu.arith(0, x)
+        _assert_same(got, np.sqrt(x), "square root against IEEE", x)
+        ss = (a[:, 0] * a[:, 0] + a[:, 1] * a[:, 1]) + a[:, 2] * a[:, 2]
+        length = np.sqrt(ss)
+        got = gpu.arith(2, a)
+        _assert_same(got, a / length[:, None], "normalise against a / sqrt(x*x + y*y + z*z)", a)
+
+
+@pytest.mark.parametrize("op", [0, 1, 2, 3])
+def test_short_forms_equal_the_compilers_over_all_bit_patterns(gpu, op):
+    # on the device: every one of the 2^32 float bit patterns as (first) operand, short form against the long one
+    assert gpu.arith_sweep(op, 0, 1 << 32) == 0
