@@ -220,7 +220,7 @@ int pt_debug_arith_sweep(pt_ctx* ctx, int op, uint32_t first_bits, uint64_t coun
 int pt_present_srgb8(pt_ctx* ctx, uint8_t* rgb8);
 
 /* The range count a render uses: settings->sample_ranges, or for 0 the largest power of two not
- * above spp_wanted / 32, within 1..8.  Progressive frames trace one sample per pixel: always 1.
+ * above spp_wanted / 16, within 1..8.  Progressive frames trace one sample per pixel: always 1.
  * Negative on a bad value.  Pure arithmetic. */
 int pt_sample_ranges(const pt_settings* settings);
 

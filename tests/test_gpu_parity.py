@@ -139,7 +139,7 @@ def test_sample_range_sums(gpu, name, w, h, spp, ranges):
     one = gpu.render(world, objs, st1)
     assert np.abs(img.astype(np.float64) - one).max() <= 4e-6, "range sums may differ from one sequence by rounding only"
     expect = api.load_core().pt_sample_ranges(C.byref(st))
-    assert expect == (ranges if ranges else 2)
+    assert expect == (ranges if ranges else 4)
 
 
 def test_per_sample_radiance_via_progressive_frames(gpu):
