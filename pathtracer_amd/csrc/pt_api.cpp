@@ -221,11 +221,16 @@ int prepare(pt_ctx* c) {
 	// one 128-byte record of eight float4 per entity (layout documented in pt_device.h)
 	const size_t np = (size_t)(n > 0 ? n : 1);
 	std::vector<float> geo(np * 8 * 4, 0.0f);
+	int features = 0;          // what the entities need of a kernel variant: 1 unit-space kinds, 2 glass, 4 roughness (FEAT_* in pt_device.h)
 	for(int i = 0; i < n; i++) {
 		const float* r = rec.data() + (size_t)i * PT_F_STRIDE;
 		int32_t type, flags;
 		memcpy(&type, r + PT_F_TYPE, 4);
 		memcpy(&flags, r + PT_F_FLAGS, 4);
+		const bool direct = (type == PT_GEOM_SPHERE && (flags & 2)) || (type == PT_GEOM_BOX && !(flags & 1));
+		if(!direct) features |= 1;
+		if(r[PT_F_IOR] != 1.0f) features |= 2;
+		if(r[PT_F_ROUGH] != 0.0f) features |= 4;
 		int32_t tf = type | (flags << 8);
 		float tf_bits;
 		memcpy(&tf_bits, &tf, 4);
@@ -340,6 +345,7 @@ int prepare(pt_ctx* c) {
 	j.scene.obj_range = c->obj_range.as<uint32_t>();
 	j.scene.cell_entries = c->cell_entries.as<float4>();
 	j.scene.coop = coop ? 1 : 0;
+	j.scene.features = features;
 	j.scene.dirs = c->dirs.as<float4>();
 	j.scene.disc = c->disc.as<float2>();
 	j.scene.samples = c->samples.as<float2>();

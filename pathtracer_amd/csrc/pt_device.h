@@ -464,7 +464,15 @@ PT_DEV float intersect_mixed(int kind, const GeoRef& g, v4f p0, v4f p3, V3 rp, V
 	return distance;
 }
 
+// What a scene contains, as far as kernel variants care: a variant compiled without a feature leaves out
+// its code and its registers; the host picks the variant from the scene (SceneDev::features).
+enum { FEAT_UNIT_KINDS = 1,     // rotated boxes, ellipsoids, cylinders, cones: the kinds that work in an entity's unit space
+       FEAT_GLASS = 2,          // an entity with a refractive index other than 1
+       FEAT_ROUGH = 4,          // an entity with roughness (Oren-Nayar)
+       FEAT_ALL = 7 };
+
 // getIntersection (code/raycast.cpp:813-893).  p0 = plane G_POS already loaded by the caller.
+template <int FEAT = FEAT_ALL>
 PT_DEV float intersect(const GeoRef& g, v4f p0, V3 rp, V3 rd, V3& pos, V3& nrm) {
 	v4f p3 = g.plane(G_DIM);
 	int tf = __float_as_int(p3.w);
@@ -473,6 +481,10 @@ PT_DEV float intersect(const GeoRef& g, v4f p0, V3 rp, V3 rd, V3& pos, V3& nrm) 
 	switch(kind_of(type, (tf >> 8) & FLAG_ROTATED, (tf >> 8) & FLAG_EVEN)) {
 		case KIND_SPHERE: return intersect_kind<KIND_SPHERE>(g, p0, p3, rp, rd, pos, nrm);
 		case KIND_BOX: return intersect_kind<KIND_BOX>(g, p0, p3, rp, rd, pos, nrm);
+		default: break;
+	}
+	if(!(FEAT & FEAT_UNIT_KINDS)) return -1;          // the scene holds no such entity
+	switch(kind_of(type, (tf >> 8) & FLAG_ROTATED, (tf >> 8) & FLAG_EVEN)) {
 		case KIND_BOX_ROTATED: return intersect_kind<KIND_BOX_ROTATED>(g, p0, p3, rp, rd, pos, nrm);
 		case KIND_ELLIPSOID: return intersect_kind<KIND_ELLIPSOID>(g, p0, p3, rp, rd, pos, nrm);
 		case KIND_CYLINDER: return intersect_kind<KIND_CYLINDER>(g, p0, p3, rp, rd, pos, nrm);
@@ -583,6 +595,7 @@ PT_DEV Surface surface_of(const Scene& sc, int index) {
 // traverse-init the reference runs before it (code/raycast.cpp:1101) only matters for `outside`.
 // The loop index is wave-uniform, so the entity records arrive through scalar loads, and the
 // surface of the winning entity is latched on the way instead of being gathered afterwards.
+template <int FEAT = FEAT_ALL>
 PT_DEV int cast_all(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface& surf) {
 	V3 entry;
 	if(!grid_entry(sc.grid, rp, rd, entry)) return 0;   // outside: only planes would be tested, and there are none
@@ -593,7 +606,7 @@ PT_DEV int cast_all(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface& 
 		v4f p0 = g.plane(G_POS);
 		if(touches_sphere(rp, rd, v3(p0.x, p0.y, p0.z), p0.w)) {
 			V3 p, q;
-			float distance = intersect(g, p0, rp, rd, p, q);
+			float distance = intersect<FEAT>(g, p0, rp, rd, p, q);
 			if(distance > 0 && distance < best) {
 				best = distance;
 				id = i + 1;
@@ -1139,13 +1152,14 @@ PT_DEV float fresnel(V3 incident, V3 normal, float ior) {
 
 // ---- one bounce of shading (code/raycast.cpp:1109-1260) -----------------------------------------
 // Returns true when the path continues.  rp/rd are updated to the next ray.
+template <int FEAT = FEAT_ALL>
 PT_DEV bool shade(const Scene& sc, FrameRef fr, int id, const Surface& surf, V3 hp, V3 hn, int bounce, V3& rp, V3& rd, V3& att, V3& col, Rng& rng) {
 	if(id != 0) {
 		v4f m0 = surf.m0, m1 = surf.m1;
 		V3 albedo = v3(m0.x, m0.y, m0.z), emit = v3(m1.x, m1.y, m1.z);
 		float refl = m0.w, ior = m1.w;
 		if(!is_zero(emit)) col = col + att * emit;
-		if(ior != 1.0f) {
+		if((FEAT & FEAT_GLASS) && ior != 1.0f) {
 			float ratio = fresnel(rd, hn, ior);
 			V3 through = refract_dir(rd, hn, ior);
 			if(is_zero(through)) ratio = 1;
@@ -1175,7 +1189,7 @@ PT_DEV bool shade(const Scene& sc, FrameRef fr, int id, const Surface& surf, V3 
 			float cosine = blend(1 - refl, 1, dot(in, hn));
 			att = ((att * albedo) / 3.14159274101257324f) * cosine;
 			float rough = surf.rough;
-			if(rough != 0.0f) {                          // Oren-Nayar (code/raycast.cpp:1199-1221)
+			if((FEAT & FEAT_ROUGH) && rough != 0.0f) {                          // Oren-Nayar (code/raycast.cpp:1199-1221)
 				float r2 = rough * rough;
 				float a = 1 - 0.5f * (r2 / (r2 + 0.33f));
 				float b = 0.45f * (r2 / (r2 + 0.09f));

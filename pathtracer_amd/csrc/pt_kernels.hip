@@ -51,8 +51,15 @@ enum { NEED_PIXEL = 0, NEED_PATH = 1, IN_FLIGHT = 2, RETIRED = 3 };
 // castRayAll for scenes under the brute-force threshold, the per-lane grid walk, or the
 // wave-cooperative grid walk (kind-binned intersections through LDS).
 enum { CAST_BRUTE = 0, CAST_GRID_LANE = 1, CAST_GRID_COOP = 2 };
-template <int MODE>
-__global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(ptl::TraceJob job) {
+// FEAT (brute-force variant only): the scene features the variant is compiled for.  A scene of even spheres and
+// unrotated boxes with opaque, smooth materials - the reference's demo scene is one - runs a variant without the
+// unit-space intersectors, Fresnel and Oren-Nayar code, which fits five wavefronts per SIMD instead of four; the
+// frame is bound by each wavefront's own instruction latencies, so the fifth wavefront is worth 13 %.
+#ifndef PT_PLAIN_WAVES_PER_SIMD
+#define PT_PLAIN_WAVES_PER_SIMD 5
+#endif
+template <int MODE, int FEAT>
+__global__ __launch_bounds__(kBlock, (MODE == CAST_BRUTE && FEAT == 0) ? PT_PLAIN_WAVES_PER_SIMD : PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(ptl::TraceJob job) {
 #ifdef PT_COOP_TIMING
 	constexpr bool kWaveLds = true;           // the phase timers live in the per-wave LDS block
 #else
@@ -91,13 +98,13 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 	int state = NEED_PIXEL;
 	int px = 0, py = 0, si = 0, si_end = 0, sample_base = 0, lens = 0;
 	size_t item = 0;                         // where the range sum goes: range * pixel slots + pixel slot
-	uint64_t pass = 0;
+	uint32_t pass = 0;
 	V3 origin = v3(0, 0, 0), sum = v3(0, 0, 0);
 	// per-lane path state
 	V3 rp = v3(0, 0, 0), rd = v3(0, 0, 1), att = v3(1, 1, 1), col = v3(0, 0, 0);
 	int bounce = 0;
 	Rng rng = { 0, 1 };
-	uint32_t casts = 0;
+	uint32_t casts = 0;                          // wave-uniform: rays cast by the whole wavefront
 	// cooperative cast only: what a lane keeps of an unfinished cast, and whether its ray is new
 	CoopLane walk_state;
 	coop_lane_reset(walk_state);
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 						si_end = ((tile_range + 1) * n_samples) >> ranges_log2;
 						pass = 0;
 					} else if(n_samples > 0) {
-						si = job.frame_index % n_samples; si_end = si + 1; pass = (uint64_t)(job.frame_index / n_samples);
+						si = job.frame_index % n_samples; si_end = si + 1; pass = (uint32_t)(job.frame_index / n_samples);
 					} else { si = 0; si_end = 0; }
 					if(si == si_end) {
 						// nothing to trace (a bucket without samples, code/raycast.cpp:1270, or fewer samples than ranges)
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 			v2f s = sc.samples[sample_base + si];
 			// the cooperative cast is short of registers: it recomputes what the other variants keep per pixel
 			const V3 from = MODE == CAST_GRID_COOP ? pixel_origin_tab(job, fr, px, py) : origin;
-			const uint64_t round = pass;
+			const uint64_t round = (uint64_t)pass;
 			camera_ray(sc, fr, from, s, lens + si, rp, rd);
 			sample_stream(fr, px, py, si, round, rng);
 			att = v3(1, 1, 1);
@@ -269,13 +276,13 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 		} else {
 			if(flying) {
 				uint64_t unused = 0;
-				id = MODE == CAST_BRUTE ? cast_all(sc, rp, rd, hp, hn, surf) : cast_grid<false>(sc, rp, rd, hp, hn, surf, unused);
+				id = MODE == CAST_BRUTE ? cast_all<FEAT>(sc, rp, rd, hp, hn, surf) : cast_grid<false>(sc, rp, rd, hp, hn, surf, unused);
 			}
 			PT_TOCK(coop, 14, t_loop);
 		}
+		casts += (uint32_t)__popcll(__ballot(landed));
 		if(landed) {
-			casts++;
-			bool alive = shade(sc, fr, id, surf, hp, hn, bounce, rp, rd, att, col, rng);
+			bool alive = shade<FEAT>(sc, fr, id, surf, hp, hn, bounce, rp, rd, att, col, rng);
 			bounce++;
 			if(!alive || bounce >= max_bounces) {
 				sum = sum + clamp_hi(col, 1.0f);            // per-sample clamp before averaging (code/raycast.cpp:1263)
@@ -306,9 +313,7 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(pt
 #endif
 	// ray-cast count: one atomic per wave
 	if(job.stats) {
-		uint32_t total = casts;
-		for(int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
-		if(lane == 0) atomicAdd((unsigned long long*)job.stats, (unsigned long long)total);
+		if(lane == 0) atomicAdd((unsigned long long*)job.stats, (unsigned long long)casts);
 	}
 }
 
@@ -531,10 +536,15 @@ int coop_stats(unsigned long long* out16) {
 }
 
 hipError_t launch_trace(const TraceJob& job, hipStream_t stream, int* grid_blocks_out) {
-	static int blocks_per_cu[3] = { 0, 0, 0 }, cus = 0;
-	static const bool lane_walk = getenv("PT_GRID_PER_LANE") != nullptr;     // A/B switch: per-lane grid walk
-	const int mode = job.scene.brute ? CAST_BRUTE : (job.scene.coop && !lane_walk ? CAST_GRID_COOP : CAST_GRID_LANE);
-	if(blocks_per_cu[mode] == 0) {
+	enum { V_BRUTE_PLAIN = 0, V_BRUTE = 1, V_GRID_LANE = 2, V_GRID_COOP = 3, V_COUNT = 4 };
+	static int blocks_per_cu[V_COUNT] = { 0, 0, 0, 0 }, cus = 0;
+	static const bool lane_walk = getenv("PT_GRID_PER_LANE") != nullptr;     // A/B switches: per-lane grid walk,
+	static const bool full_brute = getenv("PT_BRUTE_FULL") != nullptr;       // the all-features brute-force variant for every scene
+	const int variant = job.scene.brute ? (job.scene.features == 0 && !full_brute ? V_BRUTE_PLAIN : V_BRUTE)
+	                                    : (job.scene.coop && !lane_walk ? V_GRID_COOP : V_GRID_LANE);
+	void (*const kernels[V_COUNT])(TraceJob) = { pt_k_trace<CAST_BRUTE, 0>, pt_k_trace<CAST_BRUTE, FEAT_ALL>, pt_k_trace<CAST_GRID_LANE, FEAT_ALL>,
+	                                             pt_k_trace<CAST_GRID_COOP, FEAT_ALL> };
+	if(blocks_per_cu[variant] == 0) {
 		int dev = 0;
 		hipError_t e = hipGetDevice(&dev);
 		if(e != hipSuccess) return e;
@@ -543,23 +553,19 @@ hipError_t launch_trace(const TraceJob& job, hipStream_t stream, int* grid_block
 		if(e != hipSuccess) return e;
 		cus = prop.multiProcessorCount;
 		int b = 0;
-		e = mode == CAST_BRUTE ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, pt_k_trace<CAST_BRUTE>, kBlock, 0)
-		  : mode == CAST_GRID_LANE ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, pt_k_trace<CAST_GRID_LANE>, kBlock, 0)
-		  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, pt_k_trace<CAST_GRID_COOP>, kBlock, 0);
+		e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, kernels[variant], kBlock, 0);
 		if(e != hipSuccess) return e;
-		blocks_per_cu[mode] = b > 0 ? b : 1;
+		blocks_per_cu[variant] = b > 0 ? b : 1;
 	}
 	hipError_t e = hipMemsetAsync(job.group_counter, 0, (size_t)kShards * kShardStride * sizeof(uint32_t), stream);
 	if(e != hipSuccess) return e;
 	// persistent launch: every resident wave pulls groups of 64 work items until the partition is drained
 	long blocks = ((long)job.n_groups + 3) / 4;
-	long resident = (long)cus * blocks_per_cu[mode];
+	long resident = (long)cus * blocks_per_cu[variant];
 	if(blocks > resident) blocks = resident;
 	if(blocks < 1) blocks = 1;
 	if(grid_blocks_out) *grid_blocks_out = (int)blocks;
-	if(mode == CAST_BRUTE) hipLaunchKernelGGL(pt_k_trace<CAST_BRUTE>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
-	else if(mode == CAST_GRID_LANE) hipLaunchKernelGGL(pt_k_trace<CAST_GRID_LANE>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
-	else hipLaunchKernelGGL(pt_k_trace<CAST_GRID_COOP>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
+	hipLaunchKernelGGL(kernels[variant], dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
 	return hipGetLastError();
 }
 

@@ -24,6 +24,7 @@ struct SceneDev {
 	int n;
 	int brute;
 	int coop;                   // 1: the wave-cooperative cast may be used (ranges fit their packing)
+	int features;               // FEAT_* bits (pt_device.h) of what the entities need: unit-space kinds, glass, roughness
 	GridDev grid;
 };
 

@@ -158,3 +158,22 @@ def mixed_scene(seed=7, n=40, glass_share=0.3, mirror_share=0.2, rough_share=0.2
             o = make_object(pos, dim, gtype, rot=q, color=col, emit=emit)
         objs.append(o)
     return world, objs
+
+
+def plain_scene(seed=5, n=8):
+    """Even spheres and unrotated boxes with opaque, smooth materials over the demo ground box: the kind of
+    scene (like the demo scene itself) that the device renders with its leanest kernel variant."""
+    rng = PCG32(0, seed)
+    world = make_world()
+    objs = [make_object((0, 0, 0.1), (50, 50, 0.01), PT_GEOM_BOX, color=(0.5, 0.5, 0.5))]
+    for i in range(n):
+        pos = (round(rng.uniform(-12, 12), 2), round(rng.uniform(-12, 12), 2), round(rng.uniform(1, 10), 2))
+        col = (rng.uniform(0.4, 0.95), rng.uniform(0.4, 0.95), rng.uniform(0.4, 0.95))
+        refl = (0.0, 1.0, 0.6)[rng.below(3)]
+        emit = (0.9, 0.8, 0.6) if rng.below(6) == 0 else (0, 0, 0)
+        if i % 2 == 0:
+            d = rng.uniform(1.5, 5)
+            objs.append(make_object(pos, (d, d, d), PT_GEOM_SPHERE, color=col, refl=refl, emit=emit))
+        else:
+            objs.append(make_object(pos, (rng.uniform(1.5, 5), rng.uniform(1.5, 5), rng.uniform(1.5, 5)), PT_GEOM_BOX, color=col, refl=refl, emit=emit))
+    return world, objs

@@ -47,8 +47,12 @@ CASES = {
     "glass": (lambda: scenes.glass_scene(seed=3, per_type=16), 10, 10),
     "crowded": (lambda: scenes.mixed_scene(seed=9, n=300, spread=12.0), 10, 10),
     "dense2k": (lambda: scenes.dense_scene(n=2000, seed=4, half_extent=40.0, height=20.0), 24, 10),
+    # brute-force scenes (fewer than 10 entities): every kind and material, and spheres / upright boxes only
+    # (the lean kernel variant, like "default")
+    "small_mixed": (lambda: scenes.mixed_scene(seed=11, n=8), 10, 10),
+    "plain9": (lambda: scenes.plain_scene(seed=5, n=8), 10, 10),
 }
-ROUGH_FREE = {"default", "default_grid"}
+ROUGH_FREE = {"default", "default_grid", "plain9"}
 
 
 def settings_for(name, w, h, spp, bounces, seed=4242, **kw):
@@ -94,7 +98,8 @@ def test_primary_ids_and_cell_hashes(gpu, name):
 
 @pytest.mark.parametrize("name,w,h,spp,bounces", [("default", 320, 180, 16, 8), ("default_grid", 160, 90, 16, 8),
                                                    ("mixed40", 160, 90, 16, 8), ("glass", 160, 90, 16, 32),
-                                                   ("crowded", 128, 72, 4, 8), ("dense2k", 128, 72, 4, 8)])
+                                                   ("crowded", 128, 72, 4, 8), ("dense2k", 128, 72, 4, 8),
+                                                   ("small_mixed", 160, 90, 16, 16), ("plain9", 160, 90, 16, 8)])
 def test_image_parity(gpu, name, w, h, spp, bounces):
     world, objs = CASES[name][0]()
     st = settings_for(name, w, h, spp, bounces)
