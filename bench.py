@@ -88,6 +88,9 @@ def workload(name):
     if name == "dense10k-1080p-16spp-d8":
         world, objs = scenes.dense_scene(n=10000, seed=4, half_extent=90.0, height=45.0)
         return world, objs, dict(width=1920, height=1080, spp=16, bounces=8, seed=12345, grid_hint=32)
+    if name == "mixed9-1080p-64spp-d16":    # nine entities of every kind and material: the all-features brute-force kernel
+        world, objs = scenes.mixed_scene(seed=11, n=8)
+        return world, objs, dict(width=1920, height=1080, spp=64, bounces=16, seed=12345)
     m = re.fullmatch(r"demo-(\d+)x(\d+)-(\d+)spp-d(\d+)", name)
     if m:                                   # the demo scene at any size, for scaling studies
         world, objs = scenes.default_scene()
@@ -226,7 +229,7 @@ def main():
         roof = {"bound": "valu", "kernel": "pt_k_trace", "achieved": None, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                 "frac": None, "traffic": None, "kernel_ms": kernel_ms,
                 "kernel_ms_min": float(kstats.trace_ms_min), "kernel_ms_max": float(kstats.trace_ms_max)}
-        if not args.no_cpu:
+        if not args.no_cpu and world_size == 1:          # the CPU leg belongs to the one-GPU line only
             base, counters, base_paths = cpu_baseline(world, objs, kw)
             out["cpu_baseline"] = base
             flops_per_path = flops_from_counters(counters) / max(1, counters["paths"])

@@ -58,8 +58,11 @@ enum { CAST_BRUTE = 0, CAST_GRID_LANE = 1, CAST_GRID_COOP = 2 };
 #ifndef PT_PLAIN_WAVES_PER_SIMD
 #define PT_PLAIN_WAVES_PER_SIMD 5
 #endif
+#ifndef PT_BRUTE_WAVES_PER_SIMD
+#define PT_BRUTE_WAVES_PER_SIMD 5     // the all-features brute-force variant: 96 VGPRs with 16 spilled still beats four wavefronts by 7 %
+#endif
 template <int MODE, int FEAT>
-__global__ __launch_bounds__(kBlock, (MODE == CAST_BRUTE && FEAT == 0) ? PT_PLAIN_WAVES_PER_SIMD : PT_TRACE_WAVES_PER_SIMD) void pt_k_trace(ptl::TraceJob job) {
+__global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIMD : FEAT == 0 ? PT_PLAIN_WAVES_PER_SIMD : PT_BRUTE_WAVES_PER_SIMD) void pt_k_trace(ptl::TraceJob job) {
 #ifdef PT_COOP_TIMING
 	constexpr bool kWaveLds = true;           // the phase timers live in the per-wave LDS block
 #else
