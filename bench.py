@@ -88,6 +88,9 @@ def workload(name):
     if name == "dense10k-1080p-16spp-d8":
         world, objs = scenes.dense_scene(n=10000, seed=4, half_extent=90.0, height=45.0)
         return world, objs, dict(width=1920, height=1080, spp=16, bounces=8, seed=12345, grid_hint=32)
+    if name == "demo-1080p-progressive":    # interactive mode: every step is one frame of one sample per pixel, accumulated on the device
+        world, objs = scenes.default_scene()
+        return world, objs, dict(width=1920, height=1080, spp=64, bounces=8, seed=12345, frame_index=0)
     if name == "mixed9-1080p-64spp-d16":    # nine entities of every kind and material: the all-features brute-force kernel
         world, objs = scenes.mixed_scene(seed=11, n=8)
         return world, objs, dict(width=1920, height=1080, spp=64, bounces=16, seed=12345)
@@ -135,7 +138,26 @@ def cpu_baseline(world, objs, kw, budget_paths=160e6):
             dt = time.perf_counter() - t0
             out.update({"value": paths / dt / 1e6, "kind": "reference", "sample": f"{sample}, {paths} paths, {dt:.2f} s"})
     sc.close()
+    out["c1_demo_640x360_16spp"] = cpu_c1(world, objs, cores) if len(objs) < 10 else None
     return out, counters, paths
+
+
+def cpu_c1(world, objs, cores):
+    """The reference's own CPU-sized case beside it: 640x360, 16 spp, depth 8, with one worker thread and with cores-1."""
+    from oracle.oraclebind import FP, OracleScene
+    st = api.default_settings(640, 360, 16, 8, seed=12345)
+    sc = OracleScene(world, objs, st)
+    paths = sc.path_count()
+    img = np.zeros((st.height, st.width, 3), np.float32)
+    row = {"paths": paths, "kind": "port"}
+    for threads in (1, cores):
+        t0 = time.perf_counter()
+        sc.lib.pto_render_mt(sc.h, st.seed, api.PT_SEED_PER_JOB, threads, img.ctypes.data_as(FP))
+        dt = time.perf_counter() - t0
+        row[f"seconds_{threads}_threads"] = dt
+        row[f"mpaths_per_s_{threads}_threads"] = paths / dt / 1e6
+    sc.close()
+    return row
 
 
 def main():
@@ -182,6 +204,16 @@ def main():
 
         def step():
             r.trace(d_rgb=image.data_ptr(), stream=stream.cuda_stream, sync=False)
+
+    if kw.get("frame_index", -1) >= 0:
+        # progressive frames: the frame counter moves on before every trace
+        trace_step, counter = step, [0]
+
+        def step():
+            r.set_frame(counter[0])
+            counter[0] += 1
+            trace_step()
+        args.no_cpu = True
 
     for _ in range(args.warmup):
         step()
