@@ -164,7 +164,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=300)      # a fresh GPU needs half a second of work to reach its clocks (30 steps: 3 % slow)
     ap.add_argument("--workload", default="demo-1080p-64spp-d8")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--ranges", type=int, default=0, help="pt_settings.sample_ranges (0 = the library's choice)")
