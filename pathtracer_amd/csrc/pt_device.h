@@ -209,13 +209,18 @@ PT_DEV float hit_sphere(V3 lp, V3 ld, V3 sp, float sr, V3& pos, V3& nrm) {
 
 PT_DEV bool touches_sphere(V3 lp, V3 ld, V3 sp, float sr) {  // lineSphereCollision, code/rt_math.cpp:2361-2373
 	lp = lp - sp;
-	float d = dot(ld, lp);
 	float ll = dot(lp, lp);
+	float rr = sr * sr;
+	// A ray that starts well inside the sphere touches it, whatever its direction: with |lp|^2 < 0.999 r^2 and a
+	// direction no longer than 2, b = d*d - |lp|^2 + r^2 is at least 0.001 r^2 and sqrt(b) exceeds |d| by more than
+	// 1e-4 r, four orders of magnitude above the rounding errors of the reference's float arithmetic.  (The bounding
+	// sphere of a ground box holds nearly every ray origin of a scene.)  Skipped only when the whole wavefront agrees.
+	if(__ballot(!(ll < 0.999f * rr && dot(ld, ld) <= 4.0f)) == 0) return true;
+	float d = dot(ld, lp);
 	// The reference takes two square roots: b = d*d - length(lp)^2 + sr*sr must not be negative, and
 	// -d + sqrt(b) must not be negative, which is the case exactly when d <= 0 or sr*sr >= length(lp)^2.
 	// Both decisions are clear-cut for almost every ray: when the quantities are further from zero
 	// than a margin far above their rounding errors, the answer is known without the roots.
-	float rr = sr * sr;
 	float margin = 1e-5f * (d * d + ll + rr);
 	float b_est = d * d - ll + rr;
 	const bool clear_miss = b_est < -margin || (d > 0 && ll - rr > margin);
