@@ -717,8 +717,9 @@ int pt_render_progress(pt_ctx* c, pt_progress* info) {
 	if(c->prepared && c->local_tiles > 0 && hipSetDevice(c->device) == hipSuccess &&
 	   hipMemcpyAsync(c->counter_host, c->counter.p, 4, hipMemcpyDeviceToHost, c->side) == hipSuccess &&
 	   hipStreamSynchronize(c->side) == hipSuccess) {
+		// the first of the counters the groups are dealt from, in turn: it has seen every n-th group handed out so far
 		uint32_t got = *c->counter_host;
-		float f = (float)got / (float)c->local_tiles;
+		float f = c->job.n_groups > 0 ? (float)got * (float)ptl::group_counter_shards() / (float)c->job.n_groups : 1.0f;
 		info->fraction = f > 1 ? 1 : f;
 		info->paths_done = (uint64_t)((double)c->stats.paths * info->fraction);
 	}

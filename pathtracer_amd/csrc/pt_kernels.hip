@@ -523,6 +523,7 @@ __global__ __launch_bounds__(kBlock) void pt_k_assemble(const float* parts, size
 namespace ptl {
 
 const char* trace_kernel_name() { return "pt_k_trace"; }
+unsigned group_counter_shards() { return kShards; }
 
 // Diagnostic build only (-DPT_COOP_STATS): copies and clears the cooperative cast's event counters.
 int coop_stats(unsigned long long* out16) {

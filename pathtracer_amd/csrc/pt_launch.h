@@ -93,6 +93,7 @@ size_t grid_scan_blocks(size_t cells);
 hipError_t launch_grid_count_scan(const GridBuildJob& job, size_t cells, hipStream_t stream);
 hipError_t launch_grid_fill(const GridBuildJob& job, size_t cells, hipStream_t stream);
 const char* trace_kernel_name();
+unsigned group_counter_shards();   // work groups are dealt from this many counters, 32 words apart, in turn: word 0 counts every n-th group
 int coop_stats(unsigned long long* out16);
 
 }  // namespace ptl

@@ -481,6 +481,20 @@ def test_start_progress_abort(gpu):
     assert p.done == 1 and p.seconds > 0
     assert all(0 <= f <= 1 for f in seen)
     assert out.shape == (1080, 1920, 3)
+    # a render left alone: the fraction polled while it runs never goes down and ends at 1
+    st3 = settings_for("glass", 1280, 720, 64, 32)
+    gpu.start(world, objs, st3)
+    polled = []
+    t0 = time.time()
+    while time.time() - t0 < 60:
+        p = gpu.progress()
+        polled.append(p.fraction)
+        if p.done:
+            break
+        time.sleep(0.001)
+    gpu.wait()
+    assert polled == sorted(polled) and polled[-1] == 1.0 and gpu.progress().aborted == 0
+    assert len(polled) < 3 or max(polled[:-1]) > 0.1, "the fraction must move while the render runs"
     # an un-aborted render of the same context afterwards is complete and correct
     st2 = settings_for("default", 160, 90, 16, 8)
     w2, o2 = scenes.default_scene()
