@@ -136,3 +136,20 @@ def test_sample_ranges_rule(core_lib):
     for bad in (3, 32, -1):
         st = default_settings(64, 36, 64, 8, sample_ranges=bad)
         assert core_lib.pt_sample_ranges(C.byref(st)) < 0
+
+
+def test_bench_workloads_and_cpu_leg():
+    """Every named benchmark workload builds its scene and settings, and the CPU leg's small case runs."""
+    import bench
+    from pathtracer_amd.api import default_settings
+    for name in ("demo-1080p-64spp-d8", "demo-640x360-16spp-d8", "glass-1080p-128spp-d32", "glass-1080p-16spp-d32",
+                 "dense10k-1080p-16spp-d8", "mixed9-1080p-64spp-d16", "demo-1080p-progressive", "demo-320x180-4spp-d2"):
+        world, objs, kw = bench.workload(name)
+        kw = dict(kw)
+        st = default_settings(kw.pop("width"), kw.pop("height"), kw.pop("spp"), kw.pop("bounces"), **kw)
+        assert st.width > 0 and len(objs) >= 2
+    world, objs, _ = bench.workload("demo-640x360-16spp-d8")
+    row = bench.cpu_c1(world, objs, 2)
+    assert row["paths"] > 0 and row["seconds_1_threads"] > 0 and row["mpaths_per_s_2_threads"] > 0
+    counters = {k: 1 for k in list(bench.FLOP_WEIGHTS) + ["uneven_sphere"]}
+    assert bench.flops_from_counters(counters) == sum(v for k, v in bench.FLOP_WEIGHTS.items() if k != "unit_space") + 3 * bench.FLOP_WEIGHTS["unit_space"]
