@@ -60,6 +60,8 @@ struct pt_ctx {
 	uint32_t* abort_flag = nullptr;      // host-pinned, read by the trace kernel
 	uint32_t* abort_flag_dev = nullptr;  // the same word as the device addresses it
 	uint32_t* counter_host = nullptr;    // host-pinned landing word for progress polls
+	int counter_set = 0;                 // which of the two sets of group counters the next launch uses
+	std::atomic<uint32_t*> counter_live{ nullptr };   // the set of the launch in flight
 	ptl::TraceJob job{};
 	size_t fb_floats = 0;
 	bool grid_built_on_device = false;
@@ -322,7 +324,9 @@ int prepare(pt_ctx* c) {
 	c->fb_floats = compact ? (size_t)c->local_tiles * 64 * 3 : (size_t)s.width * s.height * 3;
 	PT_HIP(c, c->fb.reserve(c->fb_floats * 4));
 	if(s.frame_index >= 0) PT_HIP(c, c->accum.reserve(c->fb_floats * 4));
-	PT_HIP(c, c->counter.reserve(8192));      // the launcher's group counters, one cache line each
+	PT_HIP(c, c->counter.reserve(8192));      // two sets of group counters, one cache line each; launches alternate between them
+	PT_HIP(c, hipMemsetAsync(c->counter.p, 0, 8192, c->stream));
+	c->counter_set = 0;
 	PT_HIP(c, c->stats_dev.reserve(256));
 	// range sums of every pixel slot, and the quotients x/width, y/height (the divisions of code/raycast.cpp:1050)
 	const int sum_ranges = pt_sample_ranges(&s);
@@ -455,6 +459,10 @@ int trace(pt_ctx* c, float* d_rgb, hipStream_t stream, bool sync) {
 	hipStream_t s = stream ? stream : c->stream;
 	if(++c->serial == 0) c->serial = 1;
 	job.serial = c->serial;
+	job.group_counter = c->counter.as<uint32_t>() + (size_t)c->counter_set * 1024;
+	job.group_counter_next = c->counter.as<uint32_t>() + (size_t)(c->counter_set ^ 1) * 1024;
+	c->counter_live = job.group_counter;
+	c->counter_set ^= 1;
 	hipEvent_t e0 = take_event(c), e1 = take_event(c), e2 = take_event(c);
 	if(!e0 || !e1 || !e2) return fail(c, PT_ERR_DEVICE, "hipEventCreate failed");
 	PT_HIP(c, hipEventRecord(e0, s));
@@ -715,7 +723,8 @@ int pt_render_progress(pt_ctx* c, pt_progress* info) {
 	info->seconds = std::chrono::duration<double>(now - c->t_start).count();
 	// tiles handed out so far: read the device counter through the side stream while the kernel runs
 	if(c->prepared && c->local_tiles > 0 && hipSetDevice(c->device) == hipSuccess &&
-	   hipMemcpyAsync(c->counter_host, c->counter.p, 4, hipMemcpyDeviceToHost, c->side) == hipSuccess &&
+	   c->counter_live.load() != nullptr &&
+	   hipMemcpyAsync(c->counter_host, c->counter_live.load(), 4, hipMemcpyDeviceToHost, c->side) == hipSuccess &&
 	   hipStreamSynchronize(c->side) == hipSuccess) {
 		// the first of the counters the groups are dealt from, in turn: it has seen every n-th group handed out so far
 		uint32_t got = *c->counter_host;

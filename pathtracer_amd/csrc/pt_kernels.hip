@@ -82,6 +82,8 @@ __global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIM
 	// the blue-noise bucket offsets (at most 17 words) are read at every hand-out: keep them in LDS
 	__shared__ int bucket[20];
 	if((int)threadIdx.x <= tile_w * tile_w) bucket[threadIdx.x] = sc.offsets[threadIdx.x];
+	// the counters of the launch after this one (nobody reads them before this kernel has ended)
+	if(blockIdx.x == 0 && threadIdx.x < kShards) job.group_counter_next[threadIdx.x * kShardStride] = 0u;
 	__syncthreads();
 	const int mod_magic = 65536 / tile_w + 1;   // v % tile_w for v < 16 and tile_w <= 4 without a division
 	// Staged hand-out (every variant but the cooperative cast, whose LDS share is full): the wave that fetches a
@@ -561,8 +563,6 @@ hipError_t launch_trace(const TraceJob& job, hipStream_t stream, int* grid_block
 		if(e != hipSuccess) return e;
 		blocks_per_cu[variant] = b > 0 ? b : 1;
 	}
-	hipError_t e = hipMemsetAsync(job.group_counter, 0, (size_t)kShards * kShardStride * sizeof(uint32_t), stream);
-	if(e != hipSuccess) return e;
 	// persistent launch: every resident wave pulls groups of 64 work items until the partition is drained
 	long blocks = ((long)job.n_groups + 3) / 4;
 	long resident = (long)cus * blocks_per_cu[variant];

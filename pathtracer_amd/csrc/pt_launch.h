@@ -51,7 +51,8 @@ struct TraceJob {
 	float* fb;                  // row-major image, or tile-major [local tile][64][3] when compact
 	float* accum;               // progressive accumulation buffer (same layout as fb), may be null
 	const int32_t* tile_order;  // owned tiles in the order they are dealt (dearest first), or null for index order
-	uint32_t* group_counter;    // device words (8 KB reserved), zeroed by the launcher
+	uint32_t* group_counter;    // device words: this launch's group counters, zero when it starts
+	uint32_t* group_counter_next;   // the next launch's counters, which this launch zeroes (the two sets take turns, so no fill runs between frames)
 	const volatile uint32_t* abort_flag;   // host-pinned word, non-zero = stop fetching tiles
 	uint64_t* stats;            // device: [0] ray casts
 	int tiles_x, tiles_y;
