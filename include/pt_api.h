@@ -122,7 +122,8 @@ typedef struct pt_stats {
 	int32_t cell_size[3];
 	int32_t cell_items;          /* entries in the CSR item array */
 	int32_t bounce_passes;       /* extend/shade launches of the last trace */
-	float trace_ms;              /* mean device time per pt_trace since the last synchronisation (HIP events) */
+	float trace_ms;              /* mean device time per pt_trace since the last synchronisation (HIP events; of the launches
+	                                since then the first four and every eighth are timed, PT_EVENT_EVERY=1 times all) */
 	float dominant_kernel_ms;    /* summed device time of the extend/shade kernel in the last trace */
 	float prepare_ms;            /* host flatten + grid + tables + upload */
 	float trace_ms_min;          /* fastest and slowest of the launches folded into trace_ms */

@@ -60,6 +60,7 @@ struct pt_ctx {
 	uint32_t* abort_flag = nullptr;      // host-pinned, read by the trace kernel
 	uint32_t* abort_flag_dev = nullptr;  // the same word as the device addresses it
 	uint32_t* counter_host = nullptr;    // host-pinned landing word for progress polls
+	uint64_t launches_since_readout = 0; // pt_trace calls since the statistics were last folded
 	int counter_set = 0;                 // which of the two sets of group counters the next launch uses
 	std::atomic<uint32_t*> counter_live{ nullptr };   // the set of the launch in flight
 	ptl::TraceJob job{};
@@ -463,19 +464,29 @@ int trace(pt_ctx* c, float* d_rgb, hipStream_t stream, bool sync) {
 	job.group_counter_next = c->counter.as<uint32_t>() + (size_t)(c->counter_set ^ 1) * 1024;
 	c->counter_live = job.group_counter;
 	c->counter_set ^= 1;
-	hipEvent_t e0 = take_event(c), e1 = take_event(c), e2 = take_event(c);
-	if(!e0 || !e1 || !e2) return fail(c, PT_ERR_DEVICE, "hipEventCreate failed");
-	PT_HIP(c, hipEventRecord(e0, s));
+	// HIP events around the two kernels give the statistics their durations, and cost a few microseconds of a frame
+	// that may take 200: the first four launches after every read-out are timed, then one in eight
+	// (PT_EVENT_EVERY=n changes the eight, 1 times every launch).
+	static const int every = getenv("PT_EVENT_EVERY") ? atoi(getenv("PT_EVENT_EVERY")) : 8;
+	bool timed = every <= 1 || (c->serial % (uint32_t)every) == 0;
+	if(!timed) { std::lock_guard<std::mutex> l(c->mu); timed = c->pending.size() < 4; }
+	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+	if(timed) {
+		e0 = take_event(c); e1 = take_event(c); e2 = take_event(c);
+		if(!e0 || !e1 || !e2) return fail(c, PT_ERR_DEVICE, "hipEventCreate failed");
+		PT_HIP(c, hipEventRecord(e0, s));
+	}
 	int blocks = 0;
 	PT_HIP(c, ptl::launch_trace(job, s, &blocks));
-	PT_HIP(c, hipEventRecord(e1, s));
+	if(timed) PT_HIP(c, hipEventRecord(e1, s));
 	PT_HIP(c, ptl::launch_resolve(job, c->fb_floats / 3, s));
-	PT_HIP(c, hipEventRecord(e2, s));
-	{
+	if(timed) {
+		PT_HIP(c, hipEventRecord(e2, s));
 		std::lock_guard<std::mutex> l(c->mu);
 		c->pending.push_back({ e0, e1, e2 });
-		c->stats.bounce_passes = 1;
 	}
+	c->stats.bounce_passes = 1;
+	c->launches_since_readout++;
 	if(sync) {
 		PT_HIP(c, hipStreamSynchronize(s));
 	}
@@ -491,7 +502,7 @@ int collect(pt_ctx* c) {
 	for(auto& p : pend) {
 		float ms = 0, both = 0;
 		PT_HIP(c, hipEventSynchronize(p[2]));
-		PT_HIP(c, hipEventElapsedTime(&ms, p[0], p[1]));       // the trace kernel (with its counter reset)
+		PT_HIP(c, hipEventElapsedTime(&ms, p[0], p[1]));       // the trace kernel
 		PT_HIP(c, hipEventElapsedTime(&both, p[0], p[2]));     // trace + resolve
 		sum += ms;
 		whole += both;
@@ -507,7 +518,8 @@ int collect(pt_ctx* c) {
 		c->stats.trace_ms_min = lo; c->stats.trace_ms_max = hi; c->stats.trace_launches = (int)pend.size();
 		uint64_t rays = 0;
 		PT_HIP(c, hipMemcpy(&rays, c->stats_dev.p, sizeof rays, hipMemcpyDeviceToHost));
-		c->stats.rays = rays / (uint64_t)pend.size();
+		c->stats.rays = rays / (uint64_t)(c->launches_since_readout > 0 ? c->launches_since_readout : 1);   // the device counter adds up every launch, timed or not
+		c->launches_since_readout = 0;
 		PT_HIP(c, hipMemset(c->stats_dev.p, 0, 256));
 	}
 	return PT_OK;
