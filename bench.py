@@ -193,7 +193,7 @@ def main():
     stats = r.stats()
     part_floats = r.partition_floats()
 
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream()          # a stream of its own: handle 0 (torch's default stream) would mean "the context's stream" to pt_trace
     if world_size > 1:
         # tile-major partition buffers; rank 0 gathers them and assembles the image on a side stream while
         # the next frame is traced

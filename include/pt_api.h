@@ -106,9 +106,10 @@ typedef struct pt_settings {
 typedef struct pt_progress {
 	int32_t done;                /* 1 once the frame is complete (or aborted) */
 	int32_t aborted;
-	float fraction;              /* 0..1, share of bounce passes finished */
+	float fraction;              /* 0..1, share of the frame's work groups (8x8 tile x sample range) handed out so far;
+	                                after an abort: the share of pixels that were finished */
 	double seconds;              /* since pt_render_start, the reference's processTime (code/app.cpp:1440) */
-	uint64_t paths_done;
+	uint64_t paths_done;         /* camera samples of the pixels finished so far (exact once done, aborted or not) */
 } pt_progress;
 
 typedef struct pt_stats {
@@ -121,7 +122,7 @@ typedef struct pt_stats {
 	int32_t cells[3];
 	int32_t cell_size[3];
 	int32_t cell_items;          /* entries in the CSR item array */
-	int32_t bounce_passes;       /* extend/shade launches of the last trace */
+	int32_t grid_blocks;         /* workgroups of the last trace launch (a persistent grid sized to the device) */
 	float trace_ms;              /* mean device time per pt_trace since the last synchronisation (HIP events; of the launches
 	                                since then the first four and every eighth are timed, PT_EVENT_EVERY=1 times all) */
 	float dominant_kernel_ms;    /* summed device time of the extend/shade kernel in the last trace */
@@ -155,9 +156,18 @@ int pt_render_start(pt_ctx* ctx, const pt_world* world, const pt_object* objects
 /* Replaces the per-frame poll code/app.cpp:1436-1440 (threadQueueFinished + processTime). */
 int pt_render_progress(pt_ctx* ctx, pt_progress* info);
 
-/* Replaces the Escape handler code/app.cpp:1425-1428: the flag is honoured between bounce passes;
- * the buffer content after an abort is partial, as in the reference. */
+/* Replaces the Escape handler code/app.cpp:1425-1428.  The trace kernel stops handing out work groups
+ * (one wavefront in 64 group fetches looks at the flag); pixels already in flight finish.  As in the
+ * reference, the caller's buffer is partial afterwards: pixels that were finished hold their final
+ * value, every other pixel keeps what the caller had there before pt_render_start. */
 int pt_render_abort(pt_ctx* ctx);
+
+/* Replaces the per-frame re-upload of the half-written buffer (code/app.cpp:1456-1461): copies the pixels
+ * finished so far into `rgb` (width*height*3 floats, normally the buffer given to pt_render_start; pixels
+ * not finished yet are left untouched) and reports how many there are.  Callable while a render is
+ * active, from the polling thread; after completion it copies nothing new.  Pixels become visible as
+ * the device writes their sums through to memory, so the count trails the render by a little. */
+int pt_render_snapshot(pt_ctx* ctx, float* rgb, uint64_t* pixels_done);
 
 /* Blocks until the active render is done (headless harness). Returns the render's status. */
 int pt_render_wait(pt_ctx* ctx);
@@ -169,8 +179,11 @@ int pt_render_wait(pt_ctx* ctx);
  *   pt_trace    - all device passes into a device framebuffer (code/raycast.cpp:991-1289)
  *   pt_download - device framebuffer -> host
  * d_rgb may be NULL (library-owned framebuffer) or a device pointer to width*height*3 floats;
- * hip_stream may be NULL (library stream) or a hipStream_t.  pt_trace is synchronous with
- * respect to the host only when `sync` is non-zero.
+ * hip_stream is a hipStream_t, or NULL for the context's own stream - a non-blocking stream, NOT the
+ * legacy null stream: work queued on the null stream (torch's default stream has handle 0) is not
+ * ordered against it, so a caller that orders other work against the trace passes its own stream.
+ * pt_trace is synchronous with respect to the host only when `sync` is non-zero.  It clears a pending
+ * abort request left by an aborted pt_render_start.
  */
 int pt_prepare(pt_ctx* ctx, const pt_world* world, const pt_object* objects, int n_objects,
                const pt_settings* settings);
@@ -201,9 +214,14 @@ int pt_debug_coop_stats(pt_ctx* ctx, unsigned long long* counters16);
 int pt_debug_grid(pt_ctx* ctx, uint32_t* cell_start, int cell_capacity, uint32_t* cell_items, int item_capacity,
                   uint32_t* obj_range, int* cell_total, int* item_total, int* built_on_device);
 
-/* One-ray query through the prepared scene: the editor's picking ray (code/app.cpp:1634-1637)
- * and focal-distance picker (code/app.cpp:3233-3247). Returns the 1-based id or 0. */
+/* Ray queries through the prepared scene; hit_id receives the 1-based entity id or 0, hit_pos / hit_normal
+ * (optional) the hit.  pt_cast_rays is the tracer's own cast (code/raycast.cpp:1100-1107): every entity
+ * tested under the brute-force threshold, the grid walk from it on.  pt_pick_rays is the editor's picking
+ * ray (code/app.cpp:1634-1637) and focal-distance picker (code/app.cpp:3233-3247): castRayAll with
+ * `outside` false, i.e. every entity tested whatever the scene's size, the grid not consulted. */
 int pt_cast_rays(pt_ctx* ctx, const float* origins, const float* dirs, int n,
+                 int32_t* hit_id, float* hit_pos, float* hit_normal);
+int pt_pick_rays(pt_ctx* ctx, const float* origins, const float* dirs, int n,
                  int32_t* hit_id, float* hit_pos, float* hit_normal);
 
 /* Arithmetic probes, for tests.  The device computes the reference's divisions and square roots
@@ -217,8 +235,16 @@ int pt_debug_arith(pt_ctx* ctx, int op, const float* a, const float* b, int n, f
 int pt_debug_arith_sweep(pt_ctx* ctx, int op, uint32_t first_bits, uint64_t count, uint64_t* mismatches);
 
 /* Screenshot stage code/app.cpp:1536-1552: linear float -> sRGB OETF -> 8-bit, on the device
- * framebuffer of the last trace. rgb8 holds width*height*3 bytes. */
+ * framebuffer of the last trace. rgb8 holds width*height*3 bytes.  The bytes are the reference
+ * expression's (floatToSrgb with a float pow, then colorFloatToInt; code/rt_math.cpp:3634-3640, 351-353):
+ * the encoder is monotone, so the device compares against the 255 inputs at which its output steps up,
+ * which the host finds with the C library's powf (pt_host_srgb8_thresholds). */
 int pt_present_srgb8(pt_ctx* ctx, uint8_t* rgb8);
+/* The same encoder on caller-supplied values (host pointers), and over `count` (at most 2^32) consecutive
+ * float bit patterns from first_bits: histogram256[k] = inputs encoded to k; mismatches = inputs whose
+ * code differs from a plain count of the thresholds at or below them.  For tests. */
+int pt_debug_srgb8(pt_ctx* ctx, const float* linear, size_t n, uint8_t* out);
+int pt_debug_srgb8_sweep(pt_ctx* ctx, uint32_t first_bits, uint64_t count, uint64_t* mismatches, uint64_t* histogram256);
 
 /* The range count a render uses: settings->sample_ranges, or for 0 the largest power of two not
  * above spp_wanted / 16, within 1..8.  Progressive frames trace one sample per pixel: always 1.
@@ -247,6 +273,9 @@ int pt_scene_load(const char* path, pt_world* world, pt_object* objects, int cap
 int pt_scene_save(const char* path, const pt_world* world, const pt_object* objects, int count);
 
 /* ---- host stages, exported so they can be checked without a GPU -------------------------- */
+
+/* The 255 smallest floats in [0, 1] that the screenshot encoder maps to 1 .. 255, ascending. */
+int pt_host_srgb8_thresholds(float* out255);
 
 /* Flattened per-object record: the members of Object the tracer reads, after
  * preCalcObjects (code/raycast.cpp:2064-2108). 36 floats per object in the order below. */

@@ -108,6 +108,7 @@ def load_oracle():
     _sig(lib, "pto_counters", None, VP, U64P)
     _sig(lib, "pto_counters_reset", None, VP)
     _sig(lib, "pto_srgb8", None, C.c_int, FP, U8P)
+    _sig(lib, "pto_srgb8_check", C.c_uint64, FP, C.c_uint32, C.c_uint64)
     return lib
 
 

@@ -1288,7 +1288,8 @@ int pto_traverse(const pto_scene* s, const float* rp, const float* rd, int cap, 
 void pto_cast(pto_scene* s, int n, const float* rp, const float* rd, int use_grid, int32_t* id, float* pos, float* nrm) {
 	for(int i = 0; i < n; i++) {
 		v3 p = V3(0, 0, 0), q = V3(0, 0, 0);
-		if(use_grid) id[i] = cast_grid(s, g3(rp + 3 * i), g3(rd + 3 * i), &p, &q, 0);
+		if(use_grid == 2) id[i] = cast_all(s, g3(rp + 3 * i), g3(rd + 3 * i), 0, &p, &q);   /* the editor's pick: castRayAll(pos, dir, false, ...), code/app.cpp:1637 */
+		else if(use_grid) id[i] = cast_grid(s, g3(rp + 3 * i), g3(rd + 3 * i), &p, &q, 0);
 		else {
 			walk_t w;
 			w.outside = 0;
@@ -1445,6 +1446,26 @@ void pto_counters(const pto_scene* s, uint64_t* out) { memcpy(out, &s->cnt, size
 void pto_counters_reset(pto_scene* s) { memset(&s->cnt, 0, sizeof(counters_t)); }
 
 /* Screenshot encoding: code/app.cpp:1541-1547, code/rt_math.cpp:351-353,3634-3640. */
+/* Over `count` consecutive float bit patterns from first_bits: inputs whose screenshot code (the expression of
+ * pto_srgb8 below) differs from the number of thresholds at or below them.  thr255 ascending. */
+uint64_t pto_srgb8_check(const float* thr255, uint32_t first_bits, uint64_t count) {
+	uint64_t bad = 0;
+	uint32_t reached = 0;
+	for(uint64_t k = 0; k < count; k++) {
+		uint32_t bits = first_bits + (uint32_t)k;
+		float v;
+		memcpy(&v, &bits, 4);
+		float e = v;
+		if(e < 0.0031308f) e *= 12.92f;
+		else e = 1.055f * powf(e, 1.0f / 2.4f) - 0.055f;
+		uint8_t code = (uint8_t)(char)(int)roundf(e * 255);
+		while(reached < 255 && thr255[reached] <= v) reached++;      /* inputs ascend, so the count only grows */
+		while(reached > 0 && !(thr255[reached - 1] <= v)) reached--;
+		if(code != (uint8_t)reached) bad++;
+	}
+	return bad;
+}
+
 void pto_srgb8(int n, const float* lin, uint8_t* out) {
 	for(int i = 0; i < n; i++) {
 		float v = lin[i];

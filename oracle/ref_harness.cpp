@@ -310,7 +310,9 @@ void ref_cast(int n, const float* rp, const float* rd, int use_grid, int32_t* id
 	for(int i = 0; i < n; i++) {
 		Vec3 p = vec3(0,0,0), q = vec3(0,0,0);
 		settings.spatialGrid.outside = false;
-		if(use_grid) {
+		if(use_grid == 2) {
+			id[i] = castRayAll(v3(rp+3*i), v3(rd+3*i), false, &ad->world.objects, &p, &q);   /* as the editor's pick calls it */
+		} else if(use_grid) {
 			id[i] = castRay(v3(rp+3*i), v3(rd+3*i), &settings, &ad->world.objects, &p, &q);
 		} else {
 			spatialGridTraverseInit(&settings.spatialGrid, v3(rp+3*i), v3(rd+3*i));

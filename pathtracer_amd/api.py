@@ -64,7 +64,7 @@ class pt_stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("pixels", C.c_uint64),
                 ("zero_sample_pixels", C.c_uint64), ("samples_total", C.c_int32),
                 ("objects", C.c_int32), ("cells", C.c_int32 * 3), ("cell_size", C.c_int32 * 3),
-                ("cell_items", C.c_int32), ("bounce_passes", C.c_int32), ("trace_ms", C.c_float),
+                ("cell_items", C.c_int32), ("grid_blocks", C.c_int32), ("trace_ms", C.c_float),
                 ("dominant_kernel_ms", C.c_float), ("prepare_ms", C.c_float),
                 ("trace_ms_min", C.c_float), ("trace_ms_max", C.c_float), ("trace_launches", C.c_int32)]
 
@@ -158,7 +158,12 @@ def load_core():
     lib.pt_debug_primary.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
     lib.pt_cast_rays.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
                                  C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.pt_pick_rays.argtypes = lib.pt_cast_rays.argtypes
+    lib.pt_render_snapshot.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
     lib.pt_present_srgb8.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
+    lib.pt_debug_srgb8.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_uint8)]
+    lib.pt_debug_srgb8_sweep.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.pt_host_srgb8_thresholds.argtypes = [C.POINTER(C.c_float)]
     lib.pt_debug_arith.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float)]
     lib.pt_debug_arith_sweep.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.pt_default_scene.argtypes = [C.POINTER(pt_world), C.POINTER(pt_object), C.c_int, C.POINTER(C.c_int)]
@@ -227,6 +232,13 @@ class Renderer:
         self._check(rc, "pt_render_progress")
         return p
 
+    def snapshot(self, out=None):
+        """Pixels finished so far copied into `out` (default: the image given to start); returns their count."""
+        n = C.c_uint64(0)
+        target = self._out if out is None else out
+        self._check(self.lib.pt_render_snapshot(self.ctx, fptr(target), C.byref(n)), "pt_render_snapshot")
+        return n.value
+
     def abort(self):
         self._check(self.lib.pt_render_abort(self.ctx), "pt_render_abort")
 
@@ -290,14 +302,16 @@ class Renderer:
         self._check(self.lib.pt_debug_primary(self.ctx, iptr(ids), u64ptr(hs)), "pt_debug_primary")
         return ids, hs
 
-    def cast_rays(self, origins, dirs):
+    def cast_rays(self, origins, dirs, pick=False):
+        """pick=False: the tracer's cast (pt_cast_rays); True: the editor's picking ray (pt_pick_rays)."""
         o = np.ascontiguousarray(origins, np.float32)
         d = np.ascontiguousarray(dirs, np.float32)
         n = o.shape[0]
         ids = np.zeros(n, np.int32)
         pos = np.zeros((n, 3), np.float32)
         nrm = np.zeros((n, 3), np.float32)
-        self._check(self.lib.pt_cast_rays(self.ctx, fptr(o), fptr(d), n, iptr(ids), fptr(pos), fptr(nrm)), "pt_cast_rays")
+        fn = self.lib.pt_pick_rays if pick else self.lib.pt_cast_rays
+        self._check(fn(self.ctx, fptr(o), fptr(d), n, iptr(ids), fptr(pos), fptr(nrm)), "pt_pick_rays" if pick else "pt_cast_rays")
         return ids, pos, nrm
 
     def arith(self, op, a, b=None):
@@ -319,6 +333,28 @@ class Renderer:
         out = np.zeros((s.height, s.width, 3), np.uint8)
         self._check(self.lib.pt_present_srgb8(self.ctx, u8ptr(out)), "pt_present_srgb8")
         return out
+
+
+    def srgb8(self, linear):
+        """The screenshot encoder on arbitrary float values."""
+        a = np.ascontiguousarray(linear, np.float32).ravel()
+        out = np.zeros(a.size, np.uint8)
+        self._check(self.lib.pt_debug_srgb8(self.ctx, fptr(a), a.size, u8ptr(out)), "pt_debug_srgb8")
+        return out
+
+    def srgb8_sweep(self, first_bits, count):
+        bad = C.c_uint64(0)
+        hist = np.zeros(256, np.uint64)
+        self._check(self.lib.pt_debug_srgb8_sweep(self.ctx, first_bits, count, C.byref(bad), u64ptr(hist)), "pt_debug_srgb8_sweep")
+        return bad.value, hist
+
+
+def srgb8_thresholds():
+    out = np.zeros(255, np.float32)
+    rc = load_core().pt_host_srgb8_thresholds(fptr(out))
+    if rc != 0:
+        raise PtError(f"pt_host_srgb8_thresholds failed ({rc})")
+    return out
 
 
 def save_scene(path, world, objs):

@@ -4,6 +4,7 @@
 // without a working HIP device every entry point that renders returns PT_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <array>
 #include <atomic>
 #include <chrono>
@@ -27,12 +28,13 @@ std::string g_create_error;
 struct DevBuf {
 	void* p = nullptr;
 	size_t cap = 0;
+	bool fresh = false;                  // set when reserve() had to allocate: the content is undefined until written
 	hipError_t reserve(size_t bytes) {
 		if(bytes <= cap) return hipSuccess;
 		if(p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if(e != hipSuccess) return e; }
 		size_t want = bytes < 256 ? 256 : bytes;
 		hipError_t e = hipMalloc(&p, want);
-		if(e == hipSuccess) cap = want;
+		if(e == hipSuccess) { cap = want; fresh = true; }
 		return e;
 	}
 	void release() { if(p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -53,17 +55,27 @@ struct pt_ctx {
 	pt_world world{};
 	pt_settings st{};
 	std::vector<pt_object> objs;
-	bool prepared = false;
+	std::atomic<bool> prepared{ false };
 
 	// device-resident scene
 	DevBuf geo, cell_start, cell_items, cell_entries, obj_range, partial, fracs, bbox, grid_cursor, grid_sums, tile_cost, tile_order, dirs, disc, samples, offsets, frame_dev, fb, accum, counter, stats_dev, scratch;
+	DevBuf thresholds;                   // the screenshot encoder's table
+	bool thresholds_ready = false;
+	void* snap_host = nullptr;           // pinned landing area of snapshots: two halves that take turns (poll thread only)
+	hipEvent_t snap_event[2] = { nullptr, nullptr };
+	ptl::TraceCaps caps{};               // compute units and resident workgroups per unit, of this context's device
+	hipStream_t last_stream = nullptr;   // the stream the latest pt_trace went to
 	uint32_t* abort_flag = nullptr;      // host-pinned, read by the trace kernel
 	uint32_t* abort_flag_dev = nullptr;  // the same word as the device addresses it
-	uint32_t* counter_host = nullptr;    // host-pinned landing word for progress polls
+	uint32_t* progress_word = nullptr;   // host-pinned: the trace kernel notes here how many work groups have been handed out
+	uint32_t* progress_word_dev = nullptr;
 	uint64_t launches_since_readout = 0; // pt_trace calls since the statistics were last folded
 	int counter_set = 0;                 // which of the two sets of group counters the next launch uses
-	std::atomic<uint32_t*> counter_live{ nullptr };   // the set of the launch in flight
 	ptl::TraceJob job{};
+	// what the polling thread may look at while the worker runs: a copy of the job of the launch in flight (under mu)
+	ptl::TraceJob live_job{};
+	bool live_valid = false;
+	uint64_t live_paths = 0;
 	size_t fb_floats = 0;
 	bool grid_built_on_device = false;
 	// random tables and blue-noise samples kept between renders (they depend on seed, spp_wanted, sample_grid_width)
@@ -85,8 +97,10 @@ struct pt_ctx {
 	// asynchronous render (pt_render_start)
 	std::thread worker;
 	std::atomic<int> active{ 0 }, done{ 0 }, aborted{ 0 }, status{ 0 };
+	std::atomic<uint64_t> done_pixels{ 0 }, done_paths{ 0 };   // of the finished render: pixels and camera samples that count
 	std::chrono::steady_clock::time_point t_start, t_end;
 	float* user_rgb = nullptr;
+	float fraction_shown = 0;            // poll thread: the largest fraction reported for the active render
 };
 
 namespace {
@@ -139,6 +153,7 @@ int upload(pt_ctx* c, DevBuf& b, const void* src, size_t bytes) {
 // (pt_gridbuild.hip) from the uploaded entity records.  *done is false when a cell lists more than
 // kLongestDeviceList entities: the ordering pass sorts a list with one thread, so the host builds then.
 constexpr uint32_t kLongestDeviceList = 4096;
+constexpr size_t kSnapHalfBytes = 8u << 20;      // one half of the pinned landing area of pt_render_snapshot
 int grid_build_device(pt_ctx* c, const std::vector<float>& rec, int n, const pt::GridDesc& gd, size_t* item_total, bool* done) {
 	*done = false;
 	const size_t cells = (size_t)gd.cells();
@@ -323,8 +338,15 @@ int prepare(pt_ctx* c) {
 	c->local_tiles = pt_partition_tiles(s.width, s.height, s.part_index, s.part_count);
 	const bool compact = s.part_count > 1;
 	c->fb_floats = compact ? (size_t)c->local_tiles * 64 * 3 : (size_t)s.width * s.height * 3;
-	PT_HIP(c, c->fb.reserve(c->fb_floats * 4));
-	if(s.frame_index >= 0) PT_HIP(c, c->accum.reserve(c->fb_floats * 4));
+	// Newly allocated image, accumulation and range-sum buffers start at zero: an aborted render leaves unfinished
+	// pixels as they were, and a stale word of a previous owner of the memory must not pass for a launch serial.
+	auto zeroed = [&](DevBuf& b, size_t bytes) -> hipError_t {
+		hipError_t e = b.reserve(bytes);
+		if(e == hipSuccess && b.fresh) { e = hipMemsetAsync(b.p, 0, b.cap, c->stream); b.fresh = false; }
+		return e;
+	};
+	PT_HIP(c, zeroed(c->fb, c->fb_floats * 4));
+	if(s.frame_index >= 0) PT_HIP(c, zeroed(c->accum, c->fb_floats * 4));
 	PT_HIP(c, c->counter.reserve(8192));      // two sets of group counters, one cache line each; launches alternate between them
 	PT_HIP(c, hipMemsetAsync(c->counter.p, 0, 8192, c->stream));
 	c->counter_set = 0;
@@ -333,7 +355,7 @@ int prepare(pt_ctx* c) {
 	const int sum_ranges = pt_sample_ranges(&s);
 	int ranges_log2 = 0;
 	while((1 << ranges_log2) < sum_ranges) ranges_log2++;
-	PT_HIP(c, c->partial.reserve((c->fb_floats / 3) * (size_t)sum_ranges * 16));
+	PT_HIP(c, zeroed(c->partial, (c->fb_floats / 3) * (size_t)sum_ranges * 16));
 	{
 		std::vector<float> fracs((size_t)s.width + (size_t)s.height);
 		for(int x = 0; x < s.width; x++) fracs[(size_t)x] = (float)x / (float)s.width;
@@ -453,17 +475,21 @@ int prepare(pt_ctx* c) {
 	return PT_OK;
 }
 
-int trace(pt_ctx* c, float* d_rgb, hipStream_t stream, bool sync) {
+int trace(pt_ctx* c, float* d_rgb, hipStream_t stream, bool sync, bool write_through) {
 	if(!c->prepared) return fail(c, PT_ERR_STATE, "pt_trace before pt_prepare");
 	ptl::TraceJob job = c->job;
 	if(d_rgb) job.fb = d_rgb;
 	hipStream_t s = stream ? stream : c->stream;
+	c->last_stream = s;
 	if(++c->serial == 0) c->serial = 1;
 	job.serial = c->serial;
+	job.write_through = write_through ? 1 : 0;
 	job.group_counter = c->counter.as<uint32_t>() + (size_t)c->counter_set * 1024;
 	job.group_counter_next = c->counter.as<uint32_t>() + (size_t)(c->counter_set ^ 1) * 1024;
-	c->counter_live = job.group_counter;
+	job.progress = write_through ? c->progress_word_dev : nullptr;
+	if(write_through) *c->progress_word = 0;
 	c->counter_set ^= 1;
+	{ std::lock_guard<std::mutex> l(c->mu); c->live_job = job; c->live_paths = c->stats.paths; c->live_valid = true; }
 	// HIP events around the two kernels give the statistics their durations, and cost a few microseconds of a frame
 	// that may take 200: the first four launches after every read-out are timed, then one in eight
 	// (PT_EVENT_EVERY=n changes the eight, 1 times every launch).
@@ -477,7 +503,7 @@ int trace(pt_ctx* c, float* d_rgb, hipStream_t stream, bool sync) {
 		PT_HIP(c, hipEventRecord(e0, s));
 	}
 	int blocks = 0;
-	PT_HIP(c, ptl::launch_trace(job, s, &blocks));
+	PT_HIP(c, ptl::launch_trace(job, c->caps, s, &blocks));
 	if(timed) PT_HIP(c, hipEventRecord(e1, s));
 	PT_HIP(c, ptl::launch_resolve(job, c->fb_floats / 3, s));
 	if(timed) {
@@ -485,7 +511,7 @@ int trace(pt_ctx* c, float* d_rgb, hipStream_t stream, bool sync) {
 		std::lock_guard<std::mutex> l(c->mu);
 		c->pending.push_back({ e0, e1, e2 });
 	}
-	c->stats.bounce_passes = 1;
+	c->stats.grid_blocks = blocks;
 	c->launches_since_readout++;
 	if(sync) {
 		PT_HIP(c, hipStreamSynchronize(s));
@@ -516,13 +542,65 @@ int collect(pt_ctx* c) {
 		c->stats.trace_ms = (float)(whole / pend.size());
 		c->stats.dominant_kernel_ms = (float)(sum / pend.size());
 		c->stats.trace_ms_min = lo; c->stats.trace_ms_max = hi; c->stats.trace_launches = (int)pend.size();
+		// on the library's stream: the caller has waited for every stream the launches went to
 		uint64_t rays = 0;
-		PT_HIP(c, hipMemcpy(&rays, c->stats_dev.p, sizeof rays, hipMemcpyDeviceToHost));
+		PT_HIP(c, hipMemcpyAsync(&rays, c->stats_dev.p, sizeof rays, hipMemcpyDeviceToHost, c->stream));
+		PT_HIP(c, hipMemsetAsync(c->stats_dev.p, 0, 256, c->stream));
+		PT_HIP(c, hipStreamSynchronize(c->stream));
 		c->stats.rays = rays / (uint64_t)(c->launches_since_readout > 0 ? c->launches_since_readout : 1);   // the device counter adds up every launch, timed or not
 		c->launches_since_readout = 0;
-		PT_HIP(c, hipMemset(c->stats_dev.p, 0, 256));
 	}
 	return PT_OK;
+}
+
+// Waits for every stream recent launches went to.
+int wait_launches(pt_ctx* c) {
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	if(c->last_stream && c->last_stream != c->stream) {
+		// a caller's stream that no longer exists has nothing left to wait for
+		if(hipStreamSynchronize(c->last_stream) != hipSuccess) (void)hipGetLastError();
+	}
+	return PT_OK;
+}
+
+// Copies pixels of an image in the context's device layout (row-major; tile-major [local tile][64][3] for a partition)
+// into the caller's row-major image: all of the context's pixels, or with a mask only those whose byte is set.
+// Pixels of other partitions and pixels without their mask byte are left alone.  Counts what it copied.
+void place_pixels(const pt_ctx* c, const float* src, const uint8_t* mask, float* rgb, uint64_t* pixels, uint64_t* paths) {
+	const pt_settings& s = c->st;
+	const int gw = s.sample_grid_width;
+	uint64_t n_pix = 0, n_paths = 0;
+	auto samples_of = [&](int x, int y) -> uint64_t {
+		const size_t t = (size_t)((y % gw) * gw + (x % gw));
+		const int cnt = c->offsets_host[t + 1] - c->offsets_host[t];
+		return s.frame_index >= 0 ? (cnt > 0 ? 1u : 0u) : (uint64_t)cnt;
+	};
+	if(s.part_count == 1) {
+		for(int y = 0; y < s.height; y++) {
+			const size_t row = (size_t)y * s.width;
+			for(int x = 0; x < s.width; x++) {
+				if(mask && !mask[row + x]) continue;
+				memcpy(rgb + (row + x) * 3, src + (row + x) * 3, 12);
+				n_pix++; n_paths += samples_of(x, y);
+			}
+		}
+	} else {
+		const int tiles_x = (s.width + 7) / 8;
+		for(int lt = 0; lt < c->local_tiles; lt++) {
+			const int tile = lt * s.part_count + s.part_index;
+			const int x0 = (tile % tiles_x) * 8, y0 = (tile / tiles_x) * 8;
+			for(int j = 0; j < 64; j++) {
+				const int x = x0 + (j & 7), y = y0 + (j >> 3);
+				if(x >= s.width || y >= s.height) continue;
+				const size_t slot = (size_t)lt * 64 + j;
+				if(mask && !mask[slot]) continue;
+				memcpy(rgb + ((size_t)y * s.width + x) * 3, src + slot * 3, 12);
+				n_pix++; n_paths += samples_of(x, y);
+			}
+		}
+	}
+	if(pixels) *pixels = n_pix;
+	if(paths) *paths = n_paths;
 }
 
 int download(pt_ctx* c, float* rgb) {
@@ -530,22 +608,34 @@ int download(pt_ctx* c, float* rgb) {
 	if(!rgb) return fail(c, PT_ERR_ARG, "null output");
 	const pt_settings& s = c->st;
 	if(s.part_count == 1) {
-		PT_HIP(c, hipMemcpy(rgb, c->fb.p, c->fb_floats * 4, hipMemcpyDeviceToHost));
+		PT_HIP(c, hipMemcpyAsync(rgb, c->fb.p, c->fb_floats * 4, hipMemcpyDeviceToHost, c->stream));
+		PT_HIP(c, hipStreamSynchronize(c->stream));
 		return PT_OK;
 	}
 	// tile-major partition buffer -> the caller's row-major image; other partitions' pixels are left alone
 	std::vector<float> tmp(c->fb_floats);
-	PT_HIP(c, hipMemcpy(tmp.data(), c->fb.p, c->fb_floats * 4, hipMemcpyDeviceToHost));
-	const int tiles_x = (s.width + 7) / 8;
-	for(int lt = 0; lt < c->local_tiles; lt++) {
-		int tile = lt * s.part_count + s.part_index;
-		int x0 = (tile % tiles_x) * 8, y0 = (tile / tiles_x) * 8;
-		for(int j = 0; j < 64; j++) {
-			int x = x0 + (j & 7), y = y0 + (j >> 3);
-			if(x >= s.width || y >= s.height) continue;
-			memcpy(rgb + ((size_t)y * s.width + x) * 3, tmp.data() + ((size_t)lt * 64 + j) * 3, 12);
-		}
-	}
+	PT_HIP(c, hipMemcpyAsync(tmp.data(), c->fb.p, c->fb_floats * 4, hipMemcpyDeviceToHost, c->stream));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	place_pixels(c, tmp.data(), nullptr, rgb, nullptr, nullptr);
+	return PT_OK;
+}
+
+// After an aborted render: only the pixels that were finished go to the caller's image, the others keep what the
+// caller had there (the reference's buffer after Escape, code/app.cpp:1425-1428: its workers stop between pixels).
+int download_finished(pt_ctx* c, float* rgb, uint64_t* pixels, uint64_t* paths) {
+	const size_t slots = c->fb_floats / 3;
+	*pixels = 0; *paths = 0;
+	if(slots == 0) return PT_OK;
+	PT_HIP(c, c->scratch.reserve(slots));
+	ptl::TraceJob job;
+	{ std::lock_guard<std::mutex> l(c->mu); job = c->live_job; }
+	PT_HIP(c, ptl::launch_finished(job, slots, c->scratch.as<uint8_t>(), c->stream));
+	std::vector<float> img(c->fb_floats);
+	std::vector<uint8_t> mask(slots);
+	PT_HIP(c, hipMemcpyAsync(img.data(), c->fb.p, c->fb_floats * 4, hipMemcpyDeviceToHost, c->stream));
+	PT_HIP(c, hipMemcpyAsync(mask.data(), c->scratch.p, slots, hipMemcpyDeviceToHost, c->stream));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	place_pixels(c, img.data(), mask.data(), rgb, pixels, paths);
 	return PT_OK;
 }
 
@@ -553,10 +643,25 @@ void worker_main(pt_ctx* c) {
 	int rc = PT_OK;
 	if(hipSetDevice(c->device) != hipSuccess) rc = fail(c, PT_ERR_DEVICE, "hipSetDevice(%d) failed", c->device);
 	if(rc == PT_OK) rc = prepare(c);
-	if(rc == PT_OK) rc = trace(c, nullptr, nullptr, true);
+	if(rc == PT_OK) rc = trace(c, nullptr, nullptr, false, true);
+	// While the device traces, the caller's image is pinned so that the copy at the end runs at the speed of the
+	// bus: a copy into pageable memory goes through the runtime's staging buffers at a fifth of that (2.3 ms of a
+	// 4.3 ms 1080p frame).  Worth it from a megabyte up; where pinning fails the pageable copy is used.
+	const size_t bytes = (size_t)c->st.width * (size_t)c->st.height * 12;
+	bool pinned = false;
+	if(rc == PT_OK && c->st.part_count == 1 && bytes >= (1u << 20) && getenv("PT_NO_PIN") == nullptr) {
+		pinned = hipHostRegister(c->user_rgb, bytes, hipHostRegisterDefault) == hipSuccess;
+		if(!pinned) (void)hipGetLastError();
+	}
+	if(rc == PT_OK) rc = wait_launches(c);
 	if(rc == PT_OK) rc = collect(c);
-	if(rc == PT_OK) rc = download(c, c->user_rgb);
-	c->aborted.store(*c->abort_flag != 0 ? 1 : 0);
+	const bool aborted = *c->abort_flag != 0;
+	uint64_t pixels = c->stats.pixels, paths = c->stats.paths;
+	if(rc == PT_OK) rc = aborted ? download_finished(c, c->user_rgb, &pixels, &paths) : download(c, c->user_rgb);
+	if(pinned && hipHostUnregister(c->user_rgb) != hipSuccess) (void)hipGetLastError();
+	c->done_pixels.store(rc == PT_OK ? pixels : 0);
+	c->done_paths.store(rc == PT_OK ? paths : 0);
+	c->aborted.store(aborted ? 1 : 0);
 	c->t_end = std::chrono::steady_clock::now();
 	c->status.store(rc);
 	c->done.store(1);
@@ -582,11 +687,13 @@ pt_ctx* pt_create(int device) {
 	bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
 	          hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess &&
 	          hipHostMalloc((void**)&c->abort_flag, 64, hipHostMallocMapped) == hipSuccess &&
-	          hipHostMalloc((void**)&c->counter_host, 64, hipHostMallocDefault) == hipSuccess;
+	          hipHostMalloc((void**)&c->progress_word, 64, hipHostMallocMapped) == hipSuccess;
 	if(!ok) { fail(nullptr, PT_ERR_DEVICE, "stream / pinned memory creation failed: %s", hipGetErrorString(hipGetLastError())); pt_destroy(c); return nullptr; }
 	*c->abort_flag = 0;
-	*c->counter_host = 0;
+	*c->progress_word = 0;
 	if(hipHostGetDevicePointer((void**)&c->abort_flag_dev, c->abort_flag, 0) != hipSuccess) c->abort_flag_dev = c->abort_flag;
+	if(hipHostGetDevicePointer((void**)&c->progress_word_dev, c->progress_word, 0) != hipSuccess) c->progress_word_dev = c->progress_word;
+	if((e = ptl::query_trace_caps(&c->caps)) != hipSuccess) { fail(nullptr, PT_ERR_DEVICE, "occupancy query failed: %s", hipGetErrorString(e)); pt_destroy(c); return nullptr; }
 	return c;
 }
 
@@ -595,19 +702,24 @@ void pt_destroy(pt_ctx* c) {
 	if(c->active.load()) { *c->abort_flag = 1; join_worker(c); }
 	(void)hipSetDevice(c->device);
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
-	for(DevBuf* b : { &c->geo, &c->cell_start, &c->cell_items, &c->cell_entries, &c->obj_range, &c->partial, &c->fracs, &c->bbox, &c->grid_cursor, &c->grid_sums, &c->tile_cost, &c->tile_order, &c->dirs, &c->disc, &c->samples, &c->offsets, &c->frame_dev, &c->fb, &c->accum, &c->counter, &c->stats_dev, &c->scratch }) b->release();
+	for(DevBuf* b : { &c->geo, &c->cell_start, &c->cell_items, &c->cell_entries, &c->obj_range, &c->partial, &c->fracs, &c->bbox, &c->grid_cursor, &c->grid_sums, &c->tile_cost, &c->tile_order, &c->dirs, &c->disc, &c->samples, &c->offsets, &c->frame_dev, &c->fb, &c->accum, &c->counter, &c->stats_dev, &c->scratch, &c->thresholds }) b->release();
+	if(c->snap_host) (void)hipHostFree(c->snap_host);
 	for(auto& p : c->pending) for(hipEvent_t e : p) (void)hipEventDestroy(e);
 	for(hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
 	if(c->abort_flag) (void)hipHostFree(c->abort_flag);
-	if(c->counter_host) (void)hipHostFree(c->counter_host);
+	if(c->progress_word) (void)hipHostFree(c->progress_word);
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 	if(c->side) (void)hipStreamDestroy(c->side);
+	for(hipEvent_t e : c->snap_event) if(e) (void)hipEventDestroy(e);
 	delete c;
 }
 
 const char* pt_last_error(const pt_ctx* c) {
-	if(!c) return g_create_error.c_str();
-	return c->err.c_str();
+	// a copy per calling thread: the worker of an asynchronous render may set a new message meanwhile
+	thread_local std::string text;
+	if(!c) { text = g_create_error; return text.c_str(); }
+	{ std::lock_guard<std::mutex> l(const_cast<pt_ctx*>(c)->mu); text = c->err; }
+	return text.c_str();
 }
 
 void pt_default_settings(pt_settings* s) {
@@ -669,7 +781,8 @@ int pt_trace(pt_ctx* c, float* d_rgb, void* hip_stream, int sync) {
 	if(!c) return PT_ERR_ARG;
 	if(c->active.load() && !c->done.load()) return fail(c, PT_ERR_BUSY, "a render is active");
 	PT_HIP(c, hipSetDevice(c->device));
-	int rc = trace(c, d_rgb, (hipStream_t)hip_stream, sync != 0);
+	*c->abort_flag = 0;          // an aborted pt_render_start leaves the word set; no asynchronous render is active here
+	int rc = trace(c, d_rgb, (hipStream_t)hip_stream, sync != 0, false);
 	if(rc == PT_OK && sync) rc = collect(c);
 	return rc;
 }
@@ -677,8 +790,8 @@ int pt_trace(pt_ctx* c, float* d_rgb, void* hip_stream, int sync) {
 int pt_sync(pt_ctx* c) {
 	if(!c) return PT_ERR_ARG;
 	PT_HIP(c, hipSetDevice(c->device));
-	PT_HIP(c, hipStreamSynchronize(c->stream));
-	return collect(c);
+	int rc = wait_launches(c);
+	return rc ? rc : collect(c);
 }
 
 int pt_set_frame(pt_ctx* c, int frame_index) {
@@ -693,8 +806,8 @@ int pt_set_frame(pt_ctx* c, int frame_index) {
 int pt_download(pt_ctx* c, float* rgb) {
 	if(!c) return PT_ERR_ARG;
 	PT_HIP(c, hipSetDevice(c->device));
-	PT_HIP(c, hipStreamSynchronize(c->stream));
-	return download(c, rgb);
+	int rc = wait_launches(c);
+	return rc ? rc : download(c, rgb);
 }
 
 int pt_get_stats(const pt_ctx* c, pt_stats* out) {
@@ -712,7 +825,11 @@ int pt_render_start(pt_ctx* c, const pt_world* w, const pt_object* objs, int n, 
 	if(rc) return rc;
 	c->user_rgb = rgb;
 	*c->abort_flag = 0;
+	{ std::lock_guard<std::mutex> l(c->mu); c->live_valid = false; }
 	c->done.store(0); c->aborted.store(0); c->status.store(0);
+	c->done_pixels.store(0); c->done_paths.store(0);
+	c->fraction_shown = 0;
+	*c->progress_word = 0;
 	c->t_start = std::chrono::steady_clock::now();
 	c->active.store(1);
 	c->worker = std::thread(worker_main, c);
@@ -727,23 +844,108 @@ int pt_render_progress(pt_ctx* c, pt_progress* info) {
 	if(c->done.load()) {
 		info->done = 1;
 		info->aborted = c->aborted.load();
-		info->fraction = info->aborted ? 0.0f : 1.0f;
+		const uint64_t pixels = c->stats.pixels;
+		info->fraction = info->aborted ? (pixels ? (float)((double)c->done_pixels.load() / (double)pixels) : 0.0f) : 1.0f;
 		info->seconds = std::chrono::duration<double>(c->t_end - c->t_start).count();
-		info->paths_done = info->aborted ? 0 : c->stats.paths;
+		info->paths_done = c->done_paths.load();
 		return c->status.load();
 	}
 	info->seconds = std::chrono::duration<double>(now - c->t_start).count();
-	// tiles handed out so far: read the device counter through the side stream while the kernel runs
-	if(c->prepared && c->local_tiles > 0 && hipSetDevice(c->device) == hipSuccess &&
-	   c->counter_live.load() != nullptr &&
-	   hipMemcpyAsync(c->counter_host, c->counter_live.load(), 4, hipMemcpyDeviceToHost, c->side) == hipSuccess &&
-	   hipStreamSynchronize(c->side) == hipSuccess) {
-		// the first of the counters the groups are dealt from, in turn: it has seen every n-th group handed out so far
-		uint32_t got = *c->counter_host;
-		float f = c->job.n_groups > 0 ? (float)got * (float)ptl::group_counter_shards() / (float)c->job.n_groups : 1.0f;
-		info->fraction = f > 1 ? 1 : f;
-		info->paths_done = (uint64_t)((double)c->stats.paths * info->fraction);
+	// Work groups handed out so far: the trace kernel writes the number into a pinned host word every 64th group
+	// fetch, so a poll is one load.  (Nothing that runs on the device can be used for this: beside the persistent trace
+	// kernel no kernel starts before the frame ends, and the runtime copies a few bytes with a kernel.)
+	int n_groups = 0;
+	uint64_t paths = 0;
+	{
+		std::lock_guard<std::mutex> l(c->mu);
+		if(c->live_valid) { n_groups = c->live_job.n_groups; paths = c->live_paths; }
 	}
+	if(n_groups > 0) {
+		const uint32_t got = *(volatile uint32_t*)c->progress_word;
+		float f = (float)got / (float)n_groups;
+		f = f > 1 ? 1 : f;
+		if(f < c->fraction_shown) f = c->fraction_shown;         // wavefronts write in any order: never step back
+		c->fraction_shown = f;
+		info->fraction = f;
+		info->paths_done = (uint64_t)((double)paths * f);
+	}
+	return PT_OK;
+}
+
+int pt_render_snapshot(pt_ctx* c, float* rgb, uint64_t* pixels_done) {
+	if(!c) return PT_ERR_ARG;
+	if(!rgb) return fail(c, PT_ERR_ARG, "null output");
+	if(pixels_done) *pixels_done = 0;
+	if(!c->active.load()) return fail(c, PT_ERR_STATE, "no render was started");
+	if(c->done.load()) {                       // the caller's image already holds every pixel that counts
+		if(pixels_done) *pixels_done = c->done_pixels.load();
+		return c->status.load();
+	}
+	ptl::TraceJob job;
+	bool valid;
+	{ std::lock_guard<std::mutex> l(c->mu); job = c->live_job; valid = c->live_valid; }
+	if(!valid || job.frame_index >= 0 || job.slots == 0) return PT_OK;      // still setting up; progressive frames are whole frames
+	PT_HIP(c, hipSetDevice(c->device));
+	// No kernel can run beside the persistent trace kernel (it holds every register file of the chip until the frame
+	// ends; a compute unit kept free by a stream mask only serves the workgroups dealt to its own XCD).  So the copy
+	// engine fetches the range sums, slice by slice into two pinned halves that take turns, and the host folds them with
+	// the operations of pt_k_resolve: same order, IEEE division, same clamp - the same floats.
+	const int ranges = 1 << job.ranges_log2;
+	const size_t slots = job.slots;
+	const size_t per_slice = std::max<size_t>(1, std::min(slots, kSnapHalfBytes / (16 * (size_t)ranges)));
+	if(!c->snap_host) {
+		PT_HIP(c, hipHostMalloc(&c->snap_host, 2 * kSnapHalfBytes, hipHostMallocDefault));
+		for(hipEvent_t& e : c->snap_event) PT_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	}
+	const size_t slices = (slots + per_slice - 1) / per_slice;
+	auto fetch = [&](size_t k) -> hipError_t {
+		const size_t first = k * per_slice, count = std::min(per_slice, slots - first);
+		char* to = (char*)c->snap_host + (k & 1) * kSnapHalfBytes;
+		for(int r = 0; r < ranges; r++) {
+			hipError_t e = hipMemcpyAsync(to + (size_t)r * count * 16, job.partial + (size_t)r * slots + first, count * 16, hipMemcpyDeviceToHost, c->side);
+			if(e != hipSuccess) return e;
+		}
+		return hipEventRecord(c->snap_event[k & 1], c->side);
+	};
+	const pt_settings& s = c->st;
+	const int gw = s.sample_grid_width, tiles_x = (s.width + 7) / 8;
+	uint64_t pixels = 0;
+	PT_HIP(c, fetch(0));
+	for(size_t k = 0; k < slices; k++) {
+		PT_HIP(c, hipEventSynchronize(c->snap_event[k & 1]));
+		if(k + 1 < slices) PT_HIP(c, fetch(k + 1));
+		const size_t first = k * per_slice, count = std::min(per_slice, slots - first);
+		const float* sums = (const float*)((const char*)c->snap_host + (k & 1) * kSnapHalfBytes);
+		for(size_t i = 0; i < count; i++) {
+			bool whole = true;
+			float sx = 0, sy = 0, sz = 0;
+			for(int r = 0; r < ranges; r++) {
+				const float* v = sums + ((size_t)r * count + i) * 4;
+				uint32_t serial;
+				memcpy(&serial, v + 3, 4);
+				whole = whole && serial == job.serial;
+				if(r == 0) { sx = v[0]; sy = v[1]; sz = v[2]; } else { sx = sx + v[0]; sy = sy + v[1]; sz = sz + v[2]; }
+			}
+			if(!whole) continue;
+			const size_t slot = first + i;
+			int x, y;
+			if(job.compact) {
+				const int tile = (int)(slot / 64) * s.part_count + s.part_index, j = (int)(slot % 64);
+				x = (tile % tiles_x) * 8 + (j & 7); y = (tile / tiles_x) * 8 + (j >> 3);
+				if(x >= s.width || y >= s.height) continue;
+			} else { x = (int)(slot % (size_t)s.width); y = (int)(slot / (size_t)s.width); }
+			const size_t t = (size_t)((y % gw) * gw + (x % gw));
+			const int n = c->offsets_host[t + 1] - c->offsets_host[t];
+			float* o = rgb + ((size_t)y * s.width + x) * 3;
+			if(n == 0) { o[0] = 0; o[1] = 0; o[2] = 0; }
+			else {
+				const float d = (float)n, qx = sx / d, qy = sy / d, qz = sz / d;
+				o[0] = qx > 1.0f ? 1.0f : qx; o[1] = qy > 1.0f ? 1.0f : qy; o[2] = qz > 1.0f ? 1.0f : qz;
+			}
+			pixels++;
+		}
+	}
+	if(pixels_done) *pixels_done = pixels;
 	return PT_OK;
 }
 
@@ -778,9 +980,9 @@ int pt_debug_primary(pt_ctx* c, int32_t* hit_id, uint64_t* cell_hash) {
 	return PT_OK;
 }
 
-int pt_cast_rays(pt_ctx* c, const float* origins, const float* dirs, int n, int32_t* hit_id, float* hit_pos, float* hit_nrm) {
+static int cast_rays(pt_ctx* c, int mode, const float* origins, const float* dirs, int n, int32_t* hit_id, float* hit_pos, float* hit_nrm) {
 	if(!c) return PT_ERR_ARG;
-	if(!c->prepared) return fail(c, PT_ERR_STATE, "pt_cast_rays before pt_prepare");
+	if(!c->prepared) return fail(c, PT_ERR_STATE, "ray query before pt_prepare");
 	if(n < 0 || (n > 0 && (!origins || !dirs || !hit_id))) return fail(c, PT_ERR_ARG, "null argument");
 	if(n == 0) return PT_OK;
 	PT_HIP(c, hipSetDevice(c->device));
@@ -791,12 +993,20 @@ int pt_cast_rays(pt_ctx* c, const float* origins, const float* dirs, int n, int3
 	int32_t* d_id = (int32_t*)(base + 4 * v);
 	PT_HIP(c, hipMemcpyAsync(d_o, origins, v, hipMemcpyHostToDevice, c->stream));
 	PT_HIP(c, hipMemcpyAsync(d_d, dirs, v, hipMemcpyHostToDevice, c->stream));
-	PT_HIP(c, ptl::launch_cast(c->job.scene, d_o, d_d, n, d_id, d_p, d_n, c->stream));
+	PT_HIP(c, ptl::launch_cast(c->job.scene, mode, d_o, d_d, n, d_id, d_p, d_n, c->stream));
+	PT_HIP(c, hipMemcpyAsync(hit_id, d_id, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+	if(hit_pos) PT_HIP(c, hipMemcpyAsync(hit_pos, d_p, v, hipMemcpyDeviceToHost, c->stream));
+	if(hit_nrm) PT_HIP(c, hipMemcpyAsync(hit_nrm, d_n, v, hipMemcpyDeviceToHost, c->stream));
 	PT_HIP(c, hipStreamSynchronize(c->stream));
-	PT_HIP(c, hipMemcpy(hit_id, d_id, (size_t)n * 4, hipMemcpyDeviceToHost));
-	if(hit_pos) PT_HIP(c, hipMemcpy(hit_pos, d_p, v, hipMemcpyDeviceToHost));
-	if(hit_nrm) PT_HIP(c, hipMemcpy(hit_nrm, d_n, v, hipMemcpyDeviceToHost));
 	return PT_OK;
+}
+
+int pt_cast_rays(pt_ctx* c, const float* origins, const float* dirs, int n, int32_t* hit_id, float* hit_pos, float* hit_nrm) {
+	return cast_rays(c, 0, origins, dirs, n, hit_id, hit_pos, hit_nrm);
+}
+
+int pt_pick_rays(pt_ctx* c, const float* origins, const float* dirs, int n, int32_t* hit_id, float* hit_pos, float* hit_nrm) {
+	return cast_rays(c, 1, origins, dirs, n, hit_id, hit_pos, hit_nrm);
 }
 
 int pt_debug_arith(pt_ctx* c, int op, const float* a, const float* b, int n, float* out) {
@@ -828,16 +1038,68 @@ int pt_debug_arith_sweep(pt_ctx* c, int op, uint32_t first_bits, uint64_t count,
 	return PT_OK;
 }
 
+// The encoder's 255 thresholds, found once per context with the host's C library and kept on the device.
+static int srgb8_table(pt_ctx* c) {
+	if(c->thresholds_ready) return PT_OK;
+	float t[256];
+	pt::srgb8_thresholds(t);
+	t[255] = 0;
+	PT_HIP(c, c->thresholds.reserve(sizeof t));
+	PT_HIP(c, hipMemcpyAsync(c->thresholds.p, t, sizeof t, hipMemcpyHostToDevice, c->stream));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	c->thresholds_ready = true;
+	return PT_OK;
+}
+
 int pt_present_srgb8(pt_ctx* c, uint8_t* rgb8) {
 	if(!c) return PT_ERR_ARG;
 	if(!c->prepared) return fail(c, PT_ERR_STATE, "pt_present_srgb8 before pt_prepare");
 	if(!rgb8) return fail(c, PT_ERR_ARG, "null output");
 	if(c->st.part_count != 1) return fail(c, PT_ERR_STATE, "pt_present_srgb8 works on a whole image (part_count == 1)");
 	PT_HIP(c, hipSetDevice(c->device));
-	PT_HIP(c, c->scratch.reserve(c->fb_floats));
-	PT_HIP(c, ptl::launch_srgb8(c->fb.as<float>(), c->fb_floats, c->scratch.as<uint8_t>(), c->stream));
+	int rc = wait_launches(c);
+	if(rc == PT_OK) rc = srgb8_table(c);
+	if(rc) return rc;
+	PT_HIP(c, c->scratch.reserve(c->fb_floats + 16));
+	PT_HIP(c, ptl::launch_srgb8(c->fb.as<float>(), c->fb_floats, c->thresholds.as<float>(), c->scratch.as<uint8_t>(), c->stream));
+	PT_HIP(c, hipMemcpyAsync(rgb8, c->scratch.p, c->fb_floats, hipMemcpyDeviceToHost, c->stream));
 	PT_HIP(c, hipStreamSynchronize(c->stream));
-	PT_HIP(c, hipMemcpy(rgb8, c->scratch.p, c->fb_floats, hipMemcpyDeviceToHost));
+	return PT_OK;
+}
+
+int pt_debug_srgb8(pt_ctx* c, const float* linear, size_t n, uint8_t* out) {
+	if(!c) return PT_ERR_ARG;
+	if(n > 0 && (!linear || !out)) return fail(c, PT_ERR_ARG, "null argument");
+	if(n == 0) return PT_OK;
+	PT_HIP(c, hipSetDevice(c->device));
+	int rc = srgb8_table(c);
+	if(rc) return rc;
+	const size_t in_bytes = ((n * 4 + 255) / 256) * 256;
+	PT_HIP(c, c->scratch.reserve(in_bytes + n + 16));
+	float* d_in = c->scratch.as<float>();
+	uint8_t* d_out = c->scratch.as<uint8_t>() + in_bytes;
+	PT_HIP(c, hipMemcpyAsync(d_in, linear, n * 4, hipMemcpyHostToDevice, c->stream));
+	PT_HIP(c, ptl::launch_srgb8(d_in, n, c->thresholds.as<float>(), d_out, c->stream));
+	PT_HIP(c, hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, c->stream));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	return PT_OK;
+}
+
+int pt_debug_srgb8_sweep(pt_ctx* c, uint32_t first_bits, uint64_t count, uint64_t* mismatches, uint64_t* histogram256) {
+	if(!c) return PT_ERR_ARG;
+	if(!mismatches || !histogram256 || count > (1ull << 32)) return fail(c, PT_ERR_ARG, "bad argument");
+	PT_HIP(c, hipSetDevice(c->device));
+	int rc = srgb8_table(c);
+	if(rc) return rc;
+	PT_HIP(c, c->scratch.reserve(257 * 8));
+	PT_HIP(c, hipMemsetAsync(c->scratch.p, 0, 257 * 8, c->stream));
+	unsigned long long* d = c->scratch.as<unsigned long long>();
+	PT_HIP(c, ptl::launch_srgb8_sweep(first_bits, count, c->thresholds.as<float>(), d, d + 1, c->stream));
+	uint64_t host[257];
+	PT_HIP(c, hipMemcpyAsync(host, d, sizeof host, hipMemcpyDeviceToHost, c->stream));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	*mismatches = host[0];
+	memcpy(histogram256, host + 1, 256 * 8);
 	return PT_OK;
 }
 
@@ -905,6 +1167,12 @@ int pt_partition_floats(const pt_ctx* c, size_t* floats) {
 }
 
 /* ---- host stages --------------------------------------------------------------------------------- */
+
+int pt_host_srgb8_thresholds(float* out255) {
+	if(!out255) return PT_ERR_ARG;
+	pt::srgb8_thresholds(out255);
+	return PT_OK;
+}
 
 int pt_host_flatten(const pt_object* objs, int n, float* records) {
 	if(n < 0 || (n > 0 && (!objs || !records))) return PT_ERR_ARG;

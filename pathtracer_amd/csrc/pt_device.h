@@ -600,10 +600,11 @@ PT_DEV Surface surface_of(const Scene& sc, int index) {
 // traverse-init the reference runs before it (code/raycast.cpp:1101) only matters for `outside`.
 // The loop index is wave-uniform, so the entity records arrive through scalar loads, and the
 // surface of the winning entity is latched on the way instead of being gathered afterwards.
-template <int FEAT = FEAT_ALL>
+// GRID_GATE false is the editor's pick (code/app.cpp:1637, 3236): castRayAll with `outside` false, no grid involved.
+template <int FEAT = FEAT_ALL, bool GRID_GATE = true>
 PT_DEV int cast_all(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface& surf) {
 	V3 entry;
-	if(!grid_entry(sc.grid, rp, rd, entry)) return 0;   // outside: only planes would be tested, and there are none
+	if(GRID_GATE && !grid_entry(sc.grid, rp, rd, entry)) return 0;   // outside: only planes would be tested, and there are none
 	int id = 0;
 	float best = 3.402823466e+38f;
 	for(int i = 0; i < sc.n; i++) {

@@ -369,4 +369,27 @@ bool object_ranges(const float* records, int n, const GridDesc& g, std::vector<u
 	return true;
 }
 
+// ---- screenshot encoding (code/app.cpp:1541-1547) ------------------------------------------------------
+uint8_t srgb8_encode(float v) {
+	if(v < 0.0031308f) v *= 12.92f;
+	else v = 1.055f * powf(v, 1.0f / 2.4f) - 0.055f;
+	return (uint8_t)(char)(int)roundf(v * 255);
+}
+
+void srgb8_thresholds(float* out255) {
+	uint32_t from = 0;                               // bits of 0.0f; every code's first input lies at or above the previous one's
+	const uint32_t one = 0x3f800000u;                // bits of 1.0f, which encodes to 255
+	for(int code = 1; code <= 255; code++) {
+		uint32_t lo = from, hi = one;                // invariant: encode(lo) < code <= encode(hi)
+		while(hi - lo > 1) {
+			const uint32_t mid = lo + (hi - lo) / 2;
+			float f;
+			memcpy(&f, &mid, 4);
+			if(srgb8_encode(f) >= code) hi = mid; else lo = mid;
+		}
+		memcpy(out255 + (code - 1), &hi, 4);
+		from = lo;
+	}
+}
+
 }  // namespace pt

@@ -37,6 +37,15 @@ __device__ __forceinline__ int lanes_below(uint64_t mask) {
 	return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// A range sum and the serial number of the launch that wrote it: one 16-byte store.  An asynchronous render's
+// sums go straight through the caches to memory, where the copy engine finds the finished ones when the host asks
+// for a snapshot of the frame in progress.  (A vector store with cache-bypass bits; nothing else changes.)
+__device__ __forceinline__ void store_sum(const ptl::TraceJob& job, float4* at, float x, float y, float z) {
+	const v4f v = { x, y, z, __uint_as_float(job.serial) };
+	if(job.write_through) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(at), "v"(v) : "memory");
+	else *at = make_float4(v.x, v.y, v.z, v.w);
+}
+
 // Pixel centre on the image plane (code/raycast.cpp:1050-1057).  The two quotients x/width and
 // y/height come from tables the host filled with the same divisions.
 __device__ __forceinline__ V3 pixel_origin_tab(const ptl::TraceJob& job, FrameRef fr, int x, int y) {
@@ -145,9 +154,11 @@ __global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIM
 						if(cand < (uint32_t)job.n_groups) { g = cand; break; }
 						shard = (shard + 1u) % kShards;
 					}
-					if(g != 0x80000000u && (g & (kAbortPoll - 1u)) == 0u && *job.abort_flag != 0u) {
-						for(uint32_t k = 0; k < kShards; k++) atomicOr(job.group_counter + k * kShardStride, 0x80000000u);
-						g = 0x80000000u;
+					if(g != 0x80000000u && (g & (kAbortPoll - 1u)) == 0u) {
+						if(*job.abort_flag != 0u) {
+							for(uint32_t k = 0; k < kShards; k++) atomicOr(job.group_counter + k * kShardStride, 0x80000000u);
+							g = 0x80000000u;
+						} else if(job.progress) *job.progress = g + 1u;       // groups go out in index order, near enough: a posted write, nobody waits for it
 					}
 				}
 				g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIM
 						}
 						if(s0 == s1) {
 							// nothing to trace (a bucket without samples, code/raycast.cpp:1270, or fewer samples than ranges)
-							job.partial[tile_item0 + slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(job.serial));
+							store_sum(job, job.partial + tile_item0 + slot, 0.0f, 0.0f, 0.0f);
 						} else {
 							const V3 o = pixel_origin_tab(job, fr, x, y);
 							a = make_uint4((uint32_t)first, (uint32_t)s0 | ((uint32_t)s1 << 16), fr->aperture != 0.0f ? (uint32_t)lens_start(fr, x, y) : 0u, round);
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIM
 					} else { si = 0; si_end = 0; }
 					if(si == si_end) {
 						// nothing to trace (a bucket without samples, code/raycast.cpp:1270, or fewer samples than ranges)
-						job.partial[item] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(job.serial));
+						store_sum(job, job.partial + item, 0.0f, 0.0f, 0.0f);
 					} else {
 						lens = fr->aperture != 0.0f ? lens_start(fr, px, py) : 0;
 						if(MODE != CAST_GRID_COOP) origin = pixel_origin_tab(job, fr, px, py);
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIM
 				si++;
 				state = NEED_PATH;
 				if(si == si_end) {
-					job.partial[item] = make_float4(sum.x, sum.y, sum.z, __uint_as_float(job.serial));
+					store_sum(job, job.partial + item, sum.x, sum.y, sum.z);
 					state = NEED_PIXEL;
 				}
 			}
@@ -368,6 +379,24 @@ __global__ __launch_bounds__(kBlock) void pt_k_resolve(ptl::TraceJob job, size_t
 	}
 }
 
+// After an aborted render: which pixels were finished (all their range sums carry the launch's serial).  pt_k_resolve has
+// written exactly those; the host copies only them to the caller (code/app.cpp:1425-1428: the reference's workers stop
+// between pixels and leave the rest of the caller's buffer alone).
+__global__ __launch_bounds__(kBlock) void pt_k_finished(ptl::TraceJob job, size_t slots, uint8_t* mask) {
+	const size_t slot = (size_t)blockIdx.x * kBlock + threadIdx.x;
+	if(slot >= slots) return;
+	const FrameRef fr = (FrameRef)job.frame;
+	if(job.compact) {
+		const int tile = (int)(slot / kGroup) * job.part_count + job.part_index, j = (int)(slot % kGroup);
+		const int px = (tile % job.tiles_x) * 8 + (j & 7), py = (tile / job.tiles_x) * 8 + (j >> 3);
+		if(px >= fr->width || py >= fr->height) { mask[slot] = 0; return; }
+	}
+	const int ranges = 1 << job.ranges_log2;
+	bool whole = true;
+	for(int r = 0; r < ranges; r++) whole = whole && __float_as_uint(job.partial[slot + (size_t)r * slots].w) == job.serial;
+	mask[slot] = whole ? 1 : 0;
+}
+
 // Cost estimate of every owned 8x8 tile, for the order the trace kernel deals them in: the ray casts of
 // sixteen whole paths (camera sample 0 of every second pixel in x and y, traced and shaded exactly as
 // the trace kernel does), four tiles per wavefront.  Only scheduling depends on it.
@@ -433,7 +462,7 @@ __global__ __launch_bounds__(kBlock) void pt_k_primary(ptl::SceneDev scene, cons
 }
 
 // One-ray queries (picking, focal-distance probe) and the intersection-level parity tests.
-__global__ __launch_bounds__(kBlock) void pt_k_cast(ptl::SceneDev scene, const float* origins, const float* dirs, int n,
+__global__ __launch_bounds__(kBlock) void pt_k_cast(ptl::SceneDev scene, int mode, const float* origins, const float* dirs, int n,
                                                     int32_t* hit_id, float* hit_pos, float* hit_nrm) {
 	const Scene sc = scene_view(scene);
 	int i = blockIdx.x * kBlock + threadIdx.x;
@@ -443,7 +472,7 @@ __global__ __launch_bounds__(kBlock) void pt_k_cast(ptl::SceneDev scene, const f
 	V3 hp = v3(0, 0, 0), hn = v3(0, 0, 0);
 	uint64_t unused = 0;
 	Surface surf;
-	int id = cast<false>(sc, rp, rd, hp, hn, surf, unused);
+	int id = mode == 1 ? cast_all<FEAT_ALL, false>(sc, rp, rd, hp, hn, surf) : cast<false>(sc, rp, rd, hp, hn, surf, unused);
 	if(id == 0) { hp = v3(0, 0, 0); hn = v3(0, 0, 0); }
 	hit_id[i] = id;
 	if(hit_pos) { hit_pos[3 * i] = hp.x; hit_pos[3 * i + 1] = hp.y; hit_pos[3 * i + 2] = hp.z; }
@@ -497,14 +526,59 @@ __global__ __launch_bounds__(kBlock) void pt_k_arith_sweep(int op, uint32_t firs
 	if(lane_id() == 0 && bad) atomicAdd(mismatches, bad);
 }
 
-// Screenshot encoding (code/app.cpp:1541-1547, code/rt_math.cpp:351-353,3634-3640).
-__global__ __launch_bounds__(kBlock) void pt_k_srgb8(const float* rgb, size_t n, uint8_t* out) {
-	size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-	if(i >= n) return;
-	float v = rgb[i];
-	if(v < 0.0031308f) v *= 12.92f;
-	else v = 1.055f * (float)pow((double)v, (double)(1.0f / 2.4f)) - 0.055f;
-	out[i] = (uint8_t)(int)roundf(v * 255);
+// Screenshot encoding (code/app.cpp:1541-1547, code/rt_math.cpp:351-353,3634-3640).  The reference's expression
+// (a float pow from the C library, then a rounding to 0..255) is monotone with 256 outputs, so it is
+// reproduced exactly by the 255 inputs at which the output steps up: the host finds them with the same
+// C library the CPU path uses, the device counts how many of them an input has reached (eight halvings,
+// no branch).  thresholds[255] is +infinity; a NaN reaches none and encodes to 0, as on the CPU.
+__device__ __forceinline__ uint32_t srgb8_code(const float* thr, float v) {
+	uint32_t reached = 0;
+	#pragma unroll
+	for(uint32_t step = 128; step > 0; step >>= 1) reached += thr[reached + step - 1] <= v ? step : 0u;
+	return reached;
+}
+__global__ __launch_bounds__(kBlock) void pt_k_srgb8(const float* rgb, size_t n, const float* thresholds, uint8_t* out) {
+	__shared__ float thr[256];
+	thr[threadIdx.x] = threadIdx.x < 255 ? thresholds[threadIdx.x] : __builtin_inff();
+	__syncthreads();
+	// four values per thread: 16 bytes in, one word out
+	const size_t i = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+	if(i + 4 <= n) {
+		const float4 v = *(const float4*)(rgb + i);
+		const uint32_t word = srgb8_code(thr, v.x) | (srgb8_code(thr, v.y) << 8) | (srgb8_code(thr, v.z) << 16) | (srgb8_code(thr, v.w) << 24);
+		*(uint32_t*)(out + i) = word;
+	} else {
+		for(size_t k = i; k < n; k++) out[k] = (uint8_t)srgb8_code(thr, rgb[k]);
+	}
+}
+// The encoder over `count` consecutive float bit patterns from `first`: a histogram of the codes, and the number of
+// inputs whose code differs from a plain count of the thresholds at or below them.
+__global__ __launch_bounds__(kBlock) void pt_k_srgb8_sweep(uint32_t first, unsigned long long count, const float* thresholds,
+                                                           unsigned long long* mismatches, unsigned long long* histogram) {
+	__shared__ float thr[256];
+	__shared__ unsigned int hist[256];
+	thr[threadIdx.x] = threadIdx.x < 255 ? thresholds[threadIdx.x] : __builtin_inff();
+	hist[threadIdx.x] = 0;
+	__syncthreads();
+	unsigned long long bad = 0;
+	// a block walks whole chunks of 2^16 patterns, so that its LDS histogram cannot overflow a word between flushes
+	for(unsigned long long chunk = blockIdx.x; chunk * 65536ull < count; chunk += gridDim.x) {
+		const unsigned long long end = (chunk + 1) * 65536ull < count ? (chunk + 1) * 65536ull : count;
+		for(unsigned long long k = chunk * 65536ull + threadIdx.x; k < end; k += kBlock) {
+			const float v = __uint_as_float(first + (uint32_t)k);
+			const uint32_t code = srgb8_code(thr, v);
+			uint32_t plain = 0;
+			for(int t = 0; t < 255; t++) plain += thr[t] <= v ? 1u : 0u;
+			bad += code != plain ? 1 : 0;
+			atomicAdd(&hist[code], 1u);
+		}
+		__syncthreads();
+		if(hist[threadIdx.x]) atomicAdd(&histogram[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+		hist[threadIdx.x] = 0;
+		__syncthreads();
+	}
+	for(int off = 32; off > 0; off >>= 1) bad += __shfl_down(bad, off, 64);
+	if(lane_id() == 0 && bad) atomicAdd(mismatches, bad);
 }
 
 // Multi-GPU: tile-major partition buffers -> row-major image (after the framebuffer gather).
@@ -525,7 +599,6 @@ __global__ __launch_bounds__(kBlock) void pt_k_assemble(const float* parts, size
 namespace ptl {
 
 const char* trace_kernel_name() { return "pt_k_trace"; }
-unsigned group_counter_shards() { return kShards; }
 
 // Diagnostic build only (-DPT_COOP_STATS): copies and clears the cooperative cast's event counters.
 int coop_stats(unsigned long long* out16) {
@@ -541,35 +614,41 @@ int coop_stats(unsigned long long* out16) {
 #endif
 }
 
-hipError_t launch_trace(const TraceJob& job, hipStream_t stream, int* grid_blocks_out) {
-	enum { V_BRUTE_PLAIN = 0, V_BRUTE = 1, V_GRID_LANE = 2, V_GRID_COOP = 3, V_COUNT = 4 };
-	static int blocks_per_cu[V_COUNT] = { 0, 0, 0, 0 }, cus = 0;
+namespace {
+enum { V_BRUTE_PLAIN = 0, V_BRUTE = 1, V_GRID_LANE = 2, V_GRID_COOP = 3, V_COUNT = 4 };
+void (*const kTraceKernels[V_COUNT])(TraceJob) = { pt_k_trace<CAST_BRUTE, 0>, pt_k_trace<CAST_BRUTE, FEAT_ALL>, pt_k_trace<CAST_GRID_LANE, FEAT_ALL>,
+                                                   pt_k_trace<CAST_GRID_COOP, FEAT_ALL> };
+}
+
+hipError_t query_trace_caps(TraceCaps* caps) {
+	int dev = 0;
+	hipError_t e = hipGetDevice(&dev);
+	if(e != hipSuccess) return e;
+	hipDeviceProp_t prop;
+	e = hipGetDeviceProperties(&prop, dev);
+	if(e != hipSuccess) return e;
+	caps->cus = prop.multiProcessorCount;
+	for(int v = 0; v < V_COUNT; v++) {
+		int b = 0;
+		e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, kTraceKernels[v], kBlock, 0);
+		if(e != hipSuccess) return e;
+		caps->blocks_per_cu[v] = b > 0 ? b : 1;
+	}
+	return hipSuccess;
+}
+
+hipError_t launch_trace(const TraceJob& job, const TraceCaps& caps, hipStream_t stream, int* grid_blocks_out) {
 	static const bool lane_walk = getenv("PT_GRID_PER_LANE") != nullptr;     // A/B switches: per-lane grid walk,
 	static const bool full_brute = getenv("PT_BRUTE_FULL") != nullptr;       // the all-features brute-force variant for every scene
 	const int variant = job.scene.brute ? (job.scene.features == 0 && !full_brute ? V_BRUTE_PLAIN : V_BRUTE)
 	                                    : (job.scene.coop && !lane_walk ? V_GRID_COOP : V_GRID_LANE);
-	void (*const kernels[V_COUNT])(TraceJob) = { pt_k_trace<CAST_BRUTE, 0>, pt_k_trace<CAST_BRUTE, FEAT_ALL>, pt_k_trace<CAST_GRID_LANE, FEAT_ALL>,
-	                                             pt_k_trace<CAST_GRID_COOP, FEAT_ALL> };
-	if(blocks_per_cu[variant] == 0) {
-		int dev = 0;
-		hipError_t e = hipGetDevice(&dev);
-		if(e != hipSuccess) return e;
-		hipDeviceProp_t prop;
-		e = hipGetDeviceProperties(&prop, dev);
-		if(e != hipSuccess) return e;
-		cus = prop.multiProcessorCount;
-		int b = 0;
-		e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, kernels[variant], kBlock, 0);
-		if(e != hipSuccess) return e;
-		blocks_per_cu[variant] = b > 0 ? b : 1;
-	}
 	// persistent launch: every resident wave pulls groups of 64 work items until the partition is drained
 	long blocks = ((long)job.n_groups + 3) / 4;
-	long resident = (long)cus * blocks_per_cu[variant];
+	long resident = (long)caps.cus * caps.blocks_per_cu[variant];
 	if(blocks > resident) blocks = resident;
 	if(blocks < 1) blocks = 1;
 	if(grid_blocks_out) *grid_blocks_out = (int)blocks;
-	hipLaunchKernelGGL(kernels[variant], dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
+	hipLaunchKernelGGL(kTraceKernels[variant], dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
 	return hipGetLastError();
 }
 
@@ -586,16 +665,22 @@ hipError_t launch_resolve(const TraceJob& job, size_t slots, hipStream_t stream)
 	return hipGetLastError();
 }
 
+hipError_t launch_finished(const TraceJob& job, size_t slots, uint8_t* mask, hipStream_t stream) {
+	if(slots == 0) return hipSuccess;
+	hipLaunchKernelGGL(pt_k_finished, dim3((unsigned)((slots + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, job, slots, mask);
+	return hipGetLastError();
+}
+
 hipError_t launch_primary_aov(const SceneDev& sc, const FrameDev* fr, int width, int height, int32_t* hit_id, uint64_t* cell_hash, hipStream_t stream) {
 	int n = width * height;
 	hipLaunchKernelGGL(pt_k_primary, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, sc, fr, hit_id, cell_hash);
 	return hipGetLastError();
 }
 
-hipError_t launch_cast(const SceneDev& sc, const float* origins, const float* dirs, int n, int32_t* hit_id, float* hit_pos,
+hipError_t launch_cast(const SceneDev& sc, int mode, const float* origins, const float* dirs, int n, int32_t* hit_id, float* hit_pos,
                        float* hit_nrm, hipStream_t stream) {
 	if(n <= 0) return hipSuccess;
-	hipLaunchKernelGGL(pt_k_cast, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, sc, origins, dirs, n, hit_id, hit_pos, hit_nrm);
+	hipLaunchKernelGGL(pt_k_cast, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, sc, mode, origins, dirs, n, hit_id, hit_pos, hit_nrm);
 	return hipGetLastError();
 }
 
@@ -613,9 +698,19 @@ hipError_t launch_arith_sweep(int op, uint32_t first, unsigned long long count, 
 	return hipGetLastError();
 }
 
-hipError_t launch_srgb8(const float* rgb, size_t n, uint8_t* out, hipStream_t stream) {
+hipError_t launch_srgb8(const float* rgb, size_t n, const float* thresholds, uint8_t* out, hipStream_t stream) {
 	if(n == 0) return hipSuccess;
-	hipLaunchKernelGGL(pt_k_srgb8, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, rgb, n, out);
+	const size_t threads = (n + 3) / 4;
+	hipLaunchKernelGGL(pt_k_srgb8, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, rgb, n, thresholds, out);
+	return hipGetLastError();
+}
+
+hipError_t launch_srgb8_sweep(uint32_t first_bits, unsigned long long count, const float* thresholds, unsigned long long* mismatches,
+                              unsigned long long* histogram, hipStream_t stream) {
+	if(count == 0) return hipSuccess;
+	unsigned long long blocks = (count + 65535ull) / 65536ull;
+	if(blocks > 4096) blocks = 4096;
+	hipLaunchKernelGGL(pt_k_srgb8_sweep, dim3((unsigned)blocks), dim3(kBlock), 0, stream, first_bits, count, thresholds, mismatches, histogram);
 	return hipGetLastError();
 }
 

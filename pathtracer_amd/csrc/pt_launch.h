@@ -54,26 +54,40 @@ struct TraceJob {
 	uint32_t* group_counter;    // device words: this launch's group counters, zero when it starts
 	uint32_t* group_counter_next;   // the next launch's counters, which this launch zeroes (the two sets take turns, so no fill runs between frames)
 	const volatile uint32_t* abort_flag;   // host-pinned word, non-zero = stop fetching tiles
+	volatile uint32_t* progress;           // host-pinned word or null: groups handed out so far, noted at every abort poll
 	uint64_t* stats;            // device: [0] ray casts
 	int tiles_x, tiles_y;
 	int n_groups;               // tiles owned by this partition x ranges
 	int part_index, part_count;
 	int frame_index;            // -1: every sample; >= 0: one sample, progressive
 	int compact;
+	int write_through;          // 1: range sums bypass the caches on their way to memory, so that a snapshot copied out while
+	                            // the frame is being traced finds the finished ones (asynchronous renders)
 };
 
-hipError_t launch_trace(const TraceJob& job, hipStream_t stream, int* grid_blocks_out);
+// What a launch of the persistent trace kernel needs to know of the device: filled once per context, under that
+// context's device (compute units, resident workgroups per unit of each kernel variant).
+struct TraceCaps { int cus; int blocks_per_cu[4]; };
+hipError_t query_trace_caps(TraceCaps* caps);
+hipError_t launch_trace(const TraceJob& job, const TraceCaps& caps, hipStream_t stream, int* grid_blocks_out);
 hipError_t launch_resolve(const TraceJob& job, size_t slots, hipStream_t stream);
+// After an aborted launch: mask[slot] = 1 for the pixels whose range sums all carry the launch's serial (the ones
+// launch_resolve wrote), 0 for the others.
+hipError_t launch_finished(const TraceJob& job, size_t slots, uint8_t* mask, hipStream_t stream);
 hipError_t launch_tile_cost(const TraceJob& job, int local_tiles, uint16_t* cost, hipStream_t stream);   // cost: ray casts of 16 probe paths per owned tile, at most 1023
 hipError_t launch_primary_aov(const SceneDev& sc, const FrameDev* fr, int width, int height, int32_t* hit_id, uint64_t* cell_hash, hipStream_t stream);
-hipError_t launch_cast(const SceneDev& sc, const float* origins, const float* dirs, int n, int32_t* hit_id,
+// mode 0: the tracer's cast (brute force under the scene's threshold, else the grid walk); 1: the editor's pick, every
+// entity tested whatever the scene's size and whether or not the ray meets the grid (code/app.cpp:1637)
+hipError_t launch_cast(const SceneDev& sc, int mode, const float* origins, const float* dirs, int n, int32_t* hit_id,
                        float* hit_pos, float* hit_nrm, hipStream_t stream);
 // Arithmetic probes of the short division / square-root forms: op 0 root(a[i]), 1 a[3i..] / b[i], 2 normalise(a[3i..]),
 // 3 a[3i..] / pi; the sweep counts, over `count` consecutive bit patterns from `first`, results that differ from the
 // compiler's own division and sqrtf.
 hipError_t launch_arith(int op, const float* a, const float* b, int n, float* out, hipStream_t stream);
 hipError_t launch_arith_sweep(int op, uint32_t first, unsigned long long count, unsigned long long* mismatches, hipStream_t stream);
-hipError_t launch_srgb8(const float* rgb, size_t n, uint8_t* out, hipStream_t stream);
+// thresholds: 255 ascending floats, thresholds[k] = the smallest input that encodes to k + 1
+hipError_t launch_srgb8(const float* rgb, size_t n, const float* thresholds, uint8_t* out, hipStream_t stream);
+hipError_t launch_srgb8_sweep(uint32_t first_bits, unsigned long long count, const float* thresholds, unsigned long long* mismatches, unsigned long long* histogram, hipStream_t stream);
 // Tile-major partition buffers (part_count of them, each `stride` floats apart) -> row-major image.
 hipError_t launch_assemble(const float* parts, size_t stride, int part_count, int width, int height, float* rgb, hipStream_t stream);
 // Device-side grid build (pt_gridbuild.hip).
@@ -94,7 +108,6 @@ size_t grid_scan_blocks(size_t cells);
 hipError_t launch_grid_count_scan(const GridBuildJob& job, size_t cells, hipStream_t stream);
 hipError_t launch_grid_fill(const GridBuildJob& job, size_t cells, hipStream_t stream);
 const char* trace_kernel_name();
-unsigned group_counter_shards();   // work groups are dealt from this many counters, 32 words apart, in turn: word 0 counts every n-th group
 int coop_stats(unsigned long long* out16);
 
 }  // namespace ptl

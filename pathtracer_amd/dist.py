@@ -34,11 +34,15 @@ class FramePipeline:
     frame i run on a side stream.  `renderers` are this process's contexts (one per owned partition; one
     in the one-process-per-GPU case), `parts` their partition indices."""
 
-    def __init__(self, renderers, parts, part_count, width, height, rank=0, world_size=1, group=None):
+    def __init__(self, renderers, parts, part_count, width, height, rank=0, world_size=1, group=None, keep_frames=0):
         self.renderers, self.parts, self.part_count = renderers, parts, part_count
         self.width, self.height, self.rank, self.world_size, self.group = width, height, rank, world_size, group
         self.stride = partition_stride(width, height, part_count)
-        self.main = torch.cuda.current_stream()
+        # Two streams of the pipeline's own.  Not torch's current stream: the default stream has handle 0, which
+        # pt_trace takes for "the context's own stream", and events recorded on the default stream would then
+        # not cover the trace kernels at all.
+        torch.cuda.init()                # Stream() does not initialise torch's device state by itself
+        self.main = torch.cuda.Stream()
         self.side = torch.cuda.Stream()
         local = len(parts)
         self.mine = [torch.zeros(local * self.stride, dtype=torch.float32, device="cuda") for _ in range(2)]
@@ -48,6 +52,9 @@ class FramePipeline:
         self.traced = [torch.cuda.Event() for _ in range(2)]
         self.drained = [torch.cuda.Event() for _ in range(2)]
         self.frame = 0
+        # tests: a copy of every assembled frame, taken on the side stream without stopping the pipeline
+        self.kept = [torch.empty(height * width * 3, dtype=torch.float32, device="cuda") for _ in range(keep_frames)] if root else []
+        torch.cuda.synchronize()         # the buffers above were filled on the default stream
 
     def step(self):
         b = self.frame & 1
@@ -66,6 +73,8 @@ class FramePipeline:
             if self.rank == 0:
                 self.renderers[0].assemble(self.gathered[b].data_ptr(), self.stride, self.part_count, self.width, self.height,
                                            self.image.data_ptr(), self.side.cuda_stream)
+                if self.frame < len(self.kept):
+                    self.kept[self.frame].copy_(self.image, non_blocking=True)
             self.drained[b].record(self.side)
         self.frame += 1
 

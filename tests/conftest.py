@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# PyTorch first: it brings its own copy of the HIP runtime, and a process must end up with one runtime.  Loaded
+# before libptcore.so, torch's copy also serves the library (same soname); the other way round torch finds no GPU.
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

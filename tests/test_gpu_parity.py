@@ -233,7 +233,8 @@ def test_partition_invariance(gpu):
 
 def test_assemble_on_device(gpu):
     """The multi-GPU data flow on one GPU: every partition traced into a caller-owned device buffer
-    (as bench.py does with torch tensors), buffers side by side as after the gather, pt_assemble."""
+    (as bench.py does with torch tensors) on a caller-owned stream, buffers side by side as after the
+    gather, pt_assemble on the same stream."""
     import torch
     from pathtracer_amd import dist as ptdist
     world, objs = scenes.mixed_scene(seed=7, n=40)
@@ -243,40 +244,55 @@ def test_assemble_on_device(gpu):
         stride = ptdist.partition_stride(w, h, parts)
         gathered = torch.full((parts * stride,), -1.0, dtype=torch.float32, device="cuda")
         image = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
-        stream = torch.cuda.current_stream()
+        torch.cuda.synchronize()
+        stream = torch.cuda.Stream()
+        assert stream.cuda_stream != 0
         for p in range(parts):
             gpu.prepare(world, objs, settings_for("mixed40", w, h, 16, 8, part_index=p, part_count=parts))
             assert gpu.partition_floats() <= stride
             gpu.trace(d_rgb=gathered[p * stride:].data_ptr(), stream=stream.cuda_stream, sync=False)
-            ptdist.gather_parts(gathered[p * stride:(p + 1) * stride], gathered[p * stride:], stride, 0, 1)
+            gpu.sync()                   # the next prepare re-uses the context's buffers
         gpu.assemble(gathered.data_ptr(), stride, parts, w, h, image.data_ptr(), stream.cuda_stream)
-        torch.cuda.synchronize()
-        gpu.sync()
+        stream.synchronize()
         got = image.cpu().numpy().reshape(h, w, 3)
         assert (bits(got) == bits(whole)).all(), parts
 
 
 def test_pipelined_partition_frames(gpu):
-    """The double-buffered frame pipeline of the multi-GPU bench (trace on the main stream, gather and
-    assemble of the previous frame on a side stream), run here with three partitions owned by one
-    process: every frame's assembled image equals the unpartitioned render bit for bit."""
+    """The double-buffered frame pipeline of the multi-GPU bench (trace on one stream, gather and assemble of
+    the previous frame on another), run here with three partitions owned by one process.  The frames are
+    progressive ones, so every frame's image differs from the one before and a gather that read a tile buffer
+    too early, or a trace that overwrote it too soon, would show: each assembled frame must equal the same
+    frame of an unpartitioned context bit for bit.  No host synchronisation between the frames."""
     torch = pytest.importorskip("torch")
     from pathtracer_amd import dist as ptdist
     world, objs = scenes.mixed_scene(seed=7, n=40)
-    st = settings_for("mixed40", 200, 120, 8, 8)
-    whole = gpu.render(world, objs, st)
+    w, h, frames = 200, 120, 12
+    gpu.prepare(world, objs, settings_for("mixed40", w, h, 8, 8, frame_index=0))
+    want = []
+    for f in range(frames):
+        gpu.set_frame(f)
+        gpu.trace()
+        want.append(gpu.download())
+    assert not (bits(want[3]) == bits(want[4])).all()
     parts = []
     for p in range(3):
         r = api.Renderer(0)
-        r.prepare(world, objs, settings_for("mixed40", 200, 120, 8, 8, part_index=p, part_count=3))
+        r.prepare(world, objs, settings_for("mixed40", w, h, 8, 8, part_index=p, part_count=3, frame_index=0))
         parts.append(r)
-    pipe = ptdist.FramePipeline(parts, [0, 1, 2], 3, 200, 120)
-    for frame in range(5):
+    pipe = ptdist.FramePipeline(parts, [0, 1, 2], 3, w, h, keep_frames=frames)
+    for f in range(frames):
+        for r in parts:
+            r.set_frame(f)
         pipe.step()
-    img = pipe.finish().cpu().numpy().reshape(120, 200, 3)
+    last = pipe.finish().cpu().numpy().reshape(h, w, 3)
+    kept = [k.cpu().numpy().reshape(h, w, 3) for k in pipe.kept]
     for r in parts:
+        r.sync()
         r.close()
-    assert (bits(img) == bits(whole)).all()
+    for f in range(frames):
+        assert (bits(kept[f]) == bits(want[f])).all(), f
+    assert (bits(last) == bits(want[-1])).all()
 
 
 def test_headless_harness(gpu, tmp_path):
@@ -507,6 +523,11 @@ def test_start_progress_abort(gpu):
 
 
 def test_srgb8_present(gpu):
+    """Screenshot bytes are the CPU path's, bit for bit: over a rendered image, over a sample of every
+    magnitude including the neighbourhood of each step of the encoder, and - through the histogram of a
+    device sweep - over every float from 0.0 to 1.0 (the thresholds themselves are pinned to the reference's
+    expression in the CPU tests)."""
+    from oracle.oraclebind import U8P
     world, objs = scenes.default_scene()
     st = settings_for("default", 160, 90, 16, 8)
     gpu.prepare(world, objs, st)
@@ -515,11 +536,151 @@ def test_srgb8_present(gpu):
     got = gpu.present_srgb8()
     sc = OracleScene(world, objs, st)
     want = np.zeros(lin.size, np.uint8)
-    from oracle.oraclebind import U8P
     sc.lib.pto_srgb8(lin.size, P(lin), want.ctypes.data_as(U8P))
+    assert (got.ravel() == want).all()
+    thr = api.srgb8_thresholds()
+    tb = thr.view(np.uint32).astype(np.int64)
+    near = (tb[:, None] + np.arange(-2048, 2048)[None, :]).clip(0, 0x3f800000).astype(np.uint32).view(np.float32).ravel()
+    rng = np.random.default_rng(2)
+    v = np.concatenate([near, rng.random(1 << 20, dtype=np.float32), np.linspace(0, 1, 100003, dtype=np.float32),
+                        np.array([0.0, 1.0, 0.0031308, np.nan], np.float32)])[:-1]      # 4n + 3 values: the encoder's tail loop runs
+    v = np.ascontiguousarray(v, np.float32)
+    want = np.zeros(v.size, np.uint8)
+    sc.lib.pto_srgb8(v.size, P(v), want.ctypes.data_as(U8P))
     sc.close()
-    diff = np.abs(got.ravel().astype(np.int16) - want.astype(np.int16))
-    assert diff.max() <= 1 and (diff != 0).mean() < 1e-3
+    assert (gpu.srgb8(v) == want).all()
+    bad, hist = gpu.srgb8_sweep(0, 0x3f800000 + 1)
+    assert bad == 0
+    edges = np.concatenate([[0], tb, [0x3f800000 + 1]])
+    assert (hist.astype(np.int64) == np.diff(edges)).all()
+
+
+def test_pick_rays_test_every_entity(gpu):
+    """The editor's picking ray (code/app.cpp:1637) is castRayAll with `outside` false: every entity, grid or no
+    grid - also on scenes the tracer walks the grid for, and for rays that never meet the grid."""
+    for name in ("default", "mixed40", "crowded"):
+        world, objs = CASES[name][0]()
+        st = settings_for(name, 64, 36, 4, 4)
+        gpu.prepare(world, objs, st)
+        sc = OracleScene(world, objs, st)
+        n = 20000
+        o, d = scene_rays(n, 78, objs, spread=60.0)
+        ids, pos, nrm = gpu.cast_rays(o, d, pick=True)
+        rid, rpos, rnrm = np.zeros(n, np.int32), np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+        sc.lib.pto_cast(sc.h, n, P(o), P(d), 2, rid.ctypes.data_as(IP), P(rpos), P(rnrm))
+        sc.close()
+        assert (ids == rid).all() and (rid != 0).mean() > 0.25
+        hit = rid != 0
+        assert (bits(pos[hit]) == bits(rpos[hit])).all() and (bits(nrm[hit]) == bits(rnrm[hit])).all()
+
+
+def test_bounding_sphere_prefilter_on_adversarial_rays(gpu):
+    """The brute-force cast replaces the two square roots of the reference's bounding-sphere test
+    (code/rt_math.cpp:2361-2373) by margin tests wherever the answer is clear.  Rays built to sit on the margins:
+    tangent to a bounding sphere within a few ulps, origins at |lp|^2 = (0.999 +- 1e-6) r^2 and (1 +- 1e-6) r^2,
+    directions of squared length around 4, origins on the sphere looking along the tangent plane."""
+    world, objs = scenes.plain_scene(seed=5, n=8)
+    more_w, more = scenes.mixed_scene(seed=11, n=8)
+    for w_, objs_ in ((world, objs), (more_w, more)):
+        st = default_settings(64, 36, 4, 4, seed=4242)
+        gpu.prepare(w_, objs_, st)
+        sc = OracleScene(w_, objs_, st)
+        rec = np.zeros(len(objs_) * api.PT_F_STRIDE, np.float32)
+        api.load_core().pt_host_flatten(api.object_array(objs_), len(objs_), api.fptr(rec))
+        rec = rec.reshape(len(objs_), api.PT_F_STRIDE)
+        rng = np.random.default_rng(17)
+        os_, ds_ = [], []
+        for k in range(len(objs_)):
+            c = rec[k, api.F["POS"]:api.F["POS"] + 3].astype(np.float64)
+            r = float(rec[k, api.F["BRADIUS"]])
+            m = 6000
+            u = rng.normal(size=(m, 3)); u /= np.linalg.norm(u, axis=1)[:, None]
+            t = np.cross(u, rng.normal(size=(m, 3))); t /= np.linalg.norm(t, axis=1)[:, None]
+            q = m // 6
+            # tangent lines: closest approach at distance r (1 + e), e within +-4e-6, seen from 2r .. 6r away
+            e = rng.uniform(-4e-6, 4e-6, m)
+            touch = c + u * (r * (1 + e))[:, None]
+            back = rng.uniform(2, 6, m)[:, None] * r
+            o = touch - t * back
+            d = t.copy()
+            # origins at |lp|^2 = f r^2 with f around the two switch points, any direction (aimed and random)
+            f = np.where(rng.random(q) < 0.5, 0.999, 1.0) + rng.uniform(-2e-6, 2e-6, q)
+            o[q:2 * q] = c + u[q:2 * q] * (r * np.sqrt(f))[:, None]
+            d[q:2 * q] = np.where(rng.random((q, 1)) < 0.5, t[q:2 * q], -u[q:2 * q] + 0.3 * t[q:2 * q])
+            d[q:2 * q] /= np.linalg.norm(d[q:2 * q], axis=1)[:, None]
+            # the same origins with directions of squared length around 4 (the shortcut's other condition)
+            o[2 * q:3 * q] = o[q:2 * q]
+            d[2 * q:3 * q] = d[q:2 * q] * np.sqrt(4 + rng.uniform(-1e-5, 1e-5, q))[:, None]
+            # origins on the sphere, direction in the tangent plane tilted by a few ulps in or out
+            o[3 * q:4 * q] = c + u[3 * q:4 * q] * r
+            d[3 * q:4 * q] = t[3 * q:4 * q] + u[3 * q:4 * q] * rng.uniform(-3e-7, 3e-7, q)[:, None]
+            os_.append(o); ds_.append(d)
+        o = np.ascontiguousarray(np.concatenate(os_), np.float32)
+        d = np.ascontiguousarray(np.concatenate(ds_), np.float32)
+        n = o.shape[0]
+        for pick in (False, True):
+            ids, pos, nrm = gpu.cast_rays(o, d, pick=pick)
+            rid, rpos, rnrm = np.zeros(n, np.int32), np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+            sc.lib.pto_cast(sc.h, n, P(o), P(d), 2 if pick else 0, rid.ctypes.data_as(IP), P(rpos), P(rnrm))
+            assert (ids == rid).all(), f"{(ids != rid).sum()} of {n} ids differ (pick={pick})"
+            hit = rid != 0
+            assert (bits(pos[hit]) == bits(rpos[hit])).all() and (bits(nrm[hit]) == bits(rnrm[hit])).all()
+        sc.close()
+
+
+def test_abort_leaves_unfinished_pixels_alone_and_snapshots_grow(gpu):
+    """Escape in the reference (code/app.cpp:1425-1428) leaves a partly written buffer; the frame loop shows the
+    half-written buffer every frame (code/app.cpp:1456-1461).  Here: snapshots taken while a render runs hold a
+    growing number of final pixels and nothing else; after an abort exactly the finished pixels were written,
+    every other pixel keeps the caller's sentinel, and the progress record counts them."""
+    world, objs = scenes.glass_scene(seed=3, per_type=16)
+    W, H = 1920, 1080
+    st = settings_for("glass", W, H, 256, 32)             # a frame of a few hundred milliseconds
+    full = gpu.render(world, objs, st)
+    sentinel = np.float32(-7.0)
+    # a fresh context: its buffers have never held an image
+    r = api.Renderer(0)
+    out = np.full((H, W, 3), sentinel, np.float32)
+    snap = np.full_like(out, sentinel)
+    r.start(world, objs, st, out=out)
+    counts, early = [], None
+    t0 = time.time()
+    while time.time() - t0 < 60:
+        p = r.progress()
+        if p.done:
+            break
+        n = r.snapshot(snap)
+        counts.append(n)
+        if early is None and n > 0:
+            early = (n, snap.copy())
+        if n > 0.15 * W * H:
+            r.abort()
+    r.wait()
+    p = r.progress()
+    assert p.done == 1 and p.aborted == 1
+    assert counts == sorted(counts) and counts[-1] > 0.15 * W * H, "snapshots must grow while the render runs"
+    for n, image in (early, (counts[-1], snap)):
+        shown = (image != sentinel).all(axis=2)
+        assert ((image == sentinel).all(axis=2) | shown).all()
+        assert int(shown.sum()) == n                        # snapshots only ever add pixels
+        assert (bits(image[shown]) == bits(full[shown])).all(), "a snapshot pixel is not the final value"
+    assert early[0] < counts[-1]
+    written = (out != sentinel).all(axis=2)
+    untouched = (out == sentinel).all(axis=2)
+    assert (written | untouched).all()
+    assert counts[-1] <= written.sum() < W * H
+    assert (bits(out[written]) == bits(full[written])).all()
+    assert p.fraction == pytest.approx(written.sum() / (W * H), abs=1e-6)
+    sc = OracleScene(world, objs, st)
+    _, offs = sc.samples()
+    sc.close()
+    per_tile = np.diff(offs).reshape(3, 3)
+    yy, xx = np.nonzero(written)
+    assert p.paths_done == int(per_tile[yy % 3, xx % 3].sum())
+    # the resident-scene interface after an abort: pt_trace clears the request and renders the whole frame
+    r.trace()
+    assert (bits(r.download()) == bits(full)).all()
+    r.close()
 
 
 def test_argument_errors(gpu):

@@ -269,7 +269,7 @@ def test_intersection_traverse_cast(ref_lib, oracle_lib, name):
         assert ka == kb and oa.value == ob.value, i
         assert (ca[:ka] == cb[:kb]).all(), i
 
-    for use_grid in (0, 1):
+    for use_grid in (0, 1, 2):          # 2: the editor's pick, castRayAll with `outside` false (code/app.cpp:1637)
         ia, ib = np.zeros(n, np.int32), np.zeros(n, np.int32)
         ref_lib.ref_cast(n, P(o), P(d), use_grid, ia.ctypes.data_as(IP), P(pa), P(na))
         oracle_lib.pto_cast(sc.h, n, P(o), P(d), use_grid, ib.ctypes.data_as(IP), P(pb), P(nb))
@@ -337,3 +337,30 @@ def test_srgb8(ref_lib, oracle_lib):
     ref_lib.ref_srgb8(v.size, v.ctypes.data_as(FP), a.ctypes.data_as(U8P))
     oracle_lib.pto_srgb8(v.size, v.ctypes.data_as(FP), b.ctypes.data_as(U8P))
     assert (a == b).all() and a[0] == 0 and a[-1] == 255
+
+
+def test_srgb8_thresholds_against_reference(ref_lib, oracle_lib):
+    """The device encodes a screenshot channel by counting which of 255 thresholds the value has reached.  The
+    thresholds (found by the library's host side) are pinned here: the reference's own expression steps from
+    k to k + 1 exactly at threshold k, for 4096 floats either side of each, and the CPU restatement of the
+    expression agrees with the count for every float in [0, 1]."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle.oraclebind import U8P
+    from pathtracer_amd import api
+    thr = api.srgb8_thresholds()
+    assert (np.diff(thr.view(np.uint32).astype(np.int64)) > 0).all() and thr[0] > 0 and thr[-1] <= 1
+    near = (thr.view(np.uint32)[:, None].astype(np.int64) + np.arange(-4096, 4096)[None, :]).clip(0, 0x3f800000)
+    v = np.ascontiguousarray(near.astype(np.uint32).view(np.float32).ravel())
+    want = (thr[None, :] <= v[:, None]).sum(1).astype(np.uint8)
+    a, b = np.zeros(v.size, np.uint8), np.zeros(v.size, np.uint8)
+    ref_lib.ref_srgb8(v.size, v.ctypes.data_as(FP), a.ctypes.data_as(U8P))
+    oracle_lib.pto_srgb8(v.size, v.ctypes.data_as(FP), b.ctypes.data_as(U8P))
+    assert (a == want).all() and (b == want).all()
+    total, chunks = 0x3f800000 + 1, 64                  # every float bit pattern from 0.0 to 1.0
+    step = (total + chunks - 1) // chunks
+
+    def run(i):
+        first = i * step
+        return oracle_lib.pto_srgb8_check(thr.ctypes.data_as(FP), first, min(step, total - first))
+    with ThreadPoolExecutor(8) as ex:
+        assert sum(ex.map(run, range(chunks))) == 0
