@@ -224,6 +224,17 @@ int pt_cast_rays(pt_ctx* ctx, const float* origins, const float* dirs, int n,
 int pt_pick_rays(pt_ctx* ctx, const float* origins, const float* dirs, int n,
                  int32_t* hit_id, float* hit_pos, float* hit_normal);
 
+/* pt_cast_rays for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments, same
+ * results; the rays and their results are staged in an array that is part of the library's device image
+ * (208 KiB per GPU, held until the process ends) instead of a buffer the context allocates and grows, so the
+ * call contains no hipMalloc / hipFree.  At most PT_NOALLOC_MAX_RAYS rays a call (PT_ERR_LIMIT beyond).  All
+ * contexts on one GPU share that GPU's array: calls that overlap in time on one GPU race; calls one after
+ * another need nothing cleared in between (a call reads back only words it wrote itself). */
+enum { PT_NOALLOC_MAX_RAYS = 4096 };
+int pt_cast_rays_noalloc(pt_ctx* ctx, const float* origins, const float* dirs, int n,
+                         int32_t* hit_id, float* hit_pos, float* hit_normal);
+
 /* Arithmetic probes, for tests.  The device computes the reference's divisions and square roots
  * (normVec3 code/rt_math.cpp:2166-2168, lenVec3 :2130-2164, Vec3 / float :2093) with shorter instruction
  * sequences than the compiler's whenever the operands allow it; every result must still be the IEEE

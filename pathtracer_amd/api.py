@@ -159,6 +159,7 @@ def load_core():
     lib.pt_cast_rays.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
                                  C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.pt_pick_rays.argtypes = lib.pt_cast_rays.argtypes
+    lib.pt_cast_rays_noalloc.argtypes = lib.pt_cast_rays.argtypes
     lib.pt_render_snapshot.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
     lib.pt_present_srgb8.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
     lib.pt_debug_srgb8.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_uint8)]

@@ -65,6 +65,8 @@ struct pt_ctx {
 	hipEvent_t snap_event[2] = { nullptr, nullptr };
 	ptl::TraceCaps caps{};               // compute units and resident workgroups per unit, of this context's device
 	hipStream_t last_stream = nullptr;   // the stream the latest pt_trace went to
+	void* static_scratch = nullptr;      // this device's copy of the library's static staging array (pt_cast_rays_noalloc)
+	size_t static_scratch_bytes = 0;
 	uint32_t* abort_flag = nullptr;      // host-pinned, read by the trace kernel
 	uint32_t* abort_flag_dev = nullptr;  // the same word as the device addresses it
 	uint32_t* progress_word = nullptr;   // host-pinned: the trace kernel notes here how many work groups have been handed out
@@ -693,6 +695,8 @@ pt_ctx* pt_create(int device) {
 	*c->progress_word = 0;
 	if(hipHostGetDevicePointer((void**)&c->abort_flag_dev, c->abort_flag, 0) != hipSuccess) c->abort_flag_dev = c->abort_flag;
 	if(hipHostGetDevicePointer((void**)&c->progress_word_dev, c->progress_word, 0) != hipSuccess) c->progress_word_dev = c->progress_word;
+	// with this context's device current: the address of that device's copy of the static staging array
+	if((e = ptl::static_scratch(&c->static_scratch, &c->static_scratch_bytes)) != hipSuccess) { fail(nullptr, PT_ERR_DEVICE, "hipGetSymbolAddress: %s", hipGetErrorString(e)); pt_destroy(c); return nullptr; }
 	if((e = ptl::query_trace_caps(&c->caps)) != hipSuccess) { fail(nullptr, PT_ERR_DEVICE, "occupancy query failed: %s", hipGetErrorString(e)); pt_destroy(c); return nullptr; }
 	return c;
 }
@@ -1003,6 +1007,30 @@ static int cast_rays(pt_ctx* c, int mode, const float* origins, const float* dir
 
 int pt_cast_rays(pt_ctx* c, const float* origins, const float* dirs, int n, int32_t* hit_id, float* hit_pos, float* hit_nrm) {
 	return cast_rays(c, 0, origins, dirs, n, hit_id, hit_pos, hit_nrm);
+}
+
+int pt_cast_rays_noalloc(pt_ctx* c, const float* origins, const float* dirs, int n, int32_t* hit_id, float* hit_pos, float* hit_nrm) {
+	if(!c) return PT_ERR_ARG;
+	if(!c->prepared) return fail(c, PT_ERR_STATE, "ray query before pt_prepare");
+	if(n < 0 || (n > 0 && (!origins || !dirs || !hit_id))) return fail(c, PT_ERR_ARG, "null argument");
+	if(n > PT_NOALLOC_MAX_RAYS) return fail(c, PT_ERR_LIMIT, "pt_cast_rays_noalloc takes at most %d rays a call, not %d (pt_cast_rays has no limit)", PT_NOALLOC_MAX_RAYS, n);
+	if(n == 0) return PT_OK;
+	static_assert(PT_NOALLOC_MAX_RAYS == ptl::kStaticRays, "the header's limit is the staging array's");
+	if(!c->static_scratch || c->static_scratch_bytes < (size_t)PT_NOALLOC_MAX_RAYS * 52) return fail(c, PT_ERR_STATE, "the static staging area is missing");
+	PT_HIP(c, hipSetDevice(c->device));
+	// fixed places in the device's static array, whatever n is; every word a call reads back it has written itself
+	const size_t v = (size_t)n * 12, span = (size_t)PT_NOALLOC_MAX_RAYS * 12;
+	char* base = (char*)c->static_scratch;
+	float* d_o = (float*)base; float* d_d = (float*)(base + span); float* d_p = (float*)(base + 2 * span); float* d_n = (float*)(base + 3 * span);
+	int32_t* d_id = (int32_t*)(base + 4 * span);
+	PT_HIP(c, hipMemcpyAsync(d_o, origins, v, hipMemcpyHostToDevice, c->stream));
+	PT_HIP(c, hipMemcpyAsync(d_d, dirs, v, hipMemcpyHostToDevice, c->stream));
+	PT_HIP(c, ptl::launch_cast(c->job.scene, 0, d_o, d_d, n, d_id, d_p, d_n, c->stream));
+	PT_HIP(c, hipMemcpyAsync(hit_id, d_id, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+	if(hit_pos) PT_HIP(c, hipMemcpyAsync(hit_pos, d_p, v, hipMemcpyDeviceToHost, c->stream));
+	if(hit_nrm) PT_HIP(c, hipMemcpyAsync(hit_nrm, d_n, v, hipMemcpyDeviceToHost, c->stream));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	return PT_OK;
 }
 
 int pt_pick_rays(pt_ctx* c, const float* origins, const float* dirs, int n, int32_t* hit_id, float* hit_pos, float* hit_nrm) {

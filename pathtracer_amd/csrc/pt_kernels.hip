@@ -684,6 +684,21 @@ hipError_t launch_cast(const SceneDev& sc, int mode, const float* origins, const
 	return hipGetLastError();
 }
 
+// ---- ray queries for callers that cannot allocate ----------------------------------------------------------
+// Staging of pt_cast_rays_noalloc: origins, directions, hit positions, hit normals (three floats a ray each) and
+// ids of at most kStaticRays rays.  One copy of the array exists per GPU for the life of the process; host code
+// reaches it only through the address hipGetSymbolAddress reports for the current device.
+static __device__ __align__(256) unsigned char scratch[kStaticRays * 52];
+
+hipError_t static_scratch(void** ptr, size_t* bytes) {
+	void* p = nullptr;
+	hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+	if(e != hipSuccess) return e;
+	*ptr = p;
+	*bytes = sizeof scratch;
+	return hipSuccess;
+}
+
 hipError_t launch_arith(int op, const float* a, const float* b, int n, float* out, hipStream_t stream) {
 	if(n <= 0) return hipSuccess;
 	hipLaunchKernelGGL(pt_k_arith, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, op, a, b, n, out);

@@ -107,6 +107,10 @@ struct GridBuildJob {
 size_t grid_scan_blocks(size_t cells);
 hipError_t launch_grid_count_scan(const GridBuildJob& job, size_t cells, hipStream_t stream);
 hipError_t launch_grid_fill(const GridBuildJob& job, size_t cells, hipStream_t stream);
+// The statically allocated staging area of the allocation-free ray query, as the CURRENT device addresses it
+// (every GPU holds its own copy at its own address), and its size: room for kStaticRays rays.
+constexpr int kStaticRays = 4096;
+hipError_t static_scratch(void** ptr, size_t* bytes);
 const char* trace_kernel_name();
 int coop_stats(unsigned long long* out16);
 
