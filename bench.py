@@ -52,7 +52,12 @@ PEAK_SCALAR_ISSUE_TFLOPS = 78.6    # the same machine issuing plain (unfused, un
                                    # SIMD) to 66.2 (8 waves) T lane-ops/s of it
 # flop/path of the named workloads as counted by the CPU leg (oracle event counters x FLOP_WEIGHTS); used
 # when the CPU leg is skipped (--no-cpu, more than one GPU) so that the roofline block is always filled
-KNOWN_FLOPS_PER_PATH = {"demo-1080p-64spp-d8": 259.5531495662587}
+# (demo: the whole frame; the others: the same scene and samples per pixel at a reduced image size - the figure moves by
+# less than 0.1 % with the size, tests/test_host_stages.py pins the small ones)
+KNOWN_FLOPS_PER_PATH = {"demo-1080p-64spp-d8": 259.5531495662587,
+                        "glass-1080p-128spp-d32": 3655.3755324074073, "glass-1080p-16spp-d32": 3656.648076322366,
+                        "dense100k-4k-256spp-d8": 4271.193952738557, "dense100k-1080p-16spp-d8": 4270.564724633967,
+                        "dense10k-1080p-16spp-d8": 2212.231339906449, "mixed9-1080p-64spp-d16": 490.5181691834548}
 
 
 def flops_from_counters(c):
@@ -142,6 +147,26 @@ def cpu_baseline(world, objs, kw, budget_paths=160e6):
     return out, counters, paths
 
 
+def oracle_flops_per_path(world, objs, kw, budget_paths, threads=4):
+    """flop/path of a workload from the oracle's event counters, on the same scene and samples per pixel at an image
+    size cut down to about budget_paths paths."""
+    from oracle.oraclebind import FP, OracleScene
+    kw = dict(kw)
+    st = api.default_settings(kw.pop("width"), kw.pop("height"), kw.pop("spp"), kw.pop("bounces"), **kw)
+    sc = OracleScene(world, objs, st)
+    paths = sc.path_count()
+    if paths > budget_paths:
+        scale = (budget_paths / paths) ** 0.5
+        st.width, st.height = max(64, int(st.width * scale) // 16 * 16), max(36, int(st.height * scale) // 9 * 9)
+        sc.close()
+        sc = OracleScene(world, objs, st)
+    img = np.zeros((st.height, st.width, 3), np.float32)
+    sc.lib.pto_render_mt(sc.h, st.seed, api.PT_SEED_PER_JOB, threads, img.ctypes.data_as(FP))
+    counters = sc.counters()
+    sc.close()
+    return flops_from_counters(counters) / max(1, counters["paths"]), counters
+
+
 def cpu_c1(world, objs, cores):
     """The reference's own CPU-sized case beside it: 640x360, 16 spp, depth 8, with one worker thread and with cores-1."""
     from oracle.oraclebind import FP, OracleScene
@@ -160,35 +185,44 @@ def cpu_c1(world, objs, cores):
     return row
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--workload", default="demo-1080p-64spp-d8")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed steps that bring an idle GPU up to its clocks")
-    ap.add_argument("--ranges", type=int, default=0, help="pt_settings.sample_ranges (0 = the library's choice)")
-    args = ap.parse_args()
+def ms_hint(seconds, steps):
+    return seconds / max(1, steps) * 1e3
 
-    import torch
-    import torch.distributed as dist
 
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world_size != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    if world_size > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+class Env:
+    """torch, the process group and this rank's place in it."""
 
-    world, objs, kw = workload(args.workload)
+    def __init__(self, gpus):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world_size != gpus:
+            raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={self.world_size}: launch with torch.distributed.run --nproc-per-node {gpus}")
+        torch.cuda.set_device(self.local_rank)
+        if self.world_size > 1:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+
+    def max_over_ranks(self, value, op="max"):
+        if self.world_size == 1:
+            return float(value)
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+
+def measure(env, name, steps, warmup, prewarm_enabled=True, ranges=0):
+    """Prepares workload `name` on this rank's partition and times `steps` frames after `warmup` untimed ones, bracketed
+    by a barrier and a device synchronisation on both sides.  Returns what the JSON line is made of."""
+    torch, dist, world_size, rank = env.torch, env.dist, env.world_size, env.rank
+    world, objs, kw = workload(name)
     skw = dict(kw)
-    skw["sample_ranges"] = args.ranges
+    skw["sample_ranges"] = ranges
     st = api.default_settings(skw.pop("width"), skw.pop("height"), skw.pop("spp"), skw.pop("bounces"),
                               part_index=rank, part_count=world_size, **skw)
-    r = api.Renderer(local_rank)
+    r = api.Renderer(env.local_rank)
     r.prepare(world, objs, st)
     stats = r.stats()
     part_floats = r.partition_floats()
@@ -206,7 +240,8 @@ def main():
         def step():
             r.trace(d_rgb=image.data_ptr(), stream=stream.cuda_stream, sync=False)
 
-    if kw.get("frame_index", -1) >= 0:
+    progressive = kw.get("frame_index", -1) >= 0
+    if progressive:
         # progressive frames: the frame counter moves on before every trace
         trace_step, counter = step, [0]
 
@@ -214,30 +249,23 @@ def main():
             r.set_frame(counter[0])
             counter[0] += 1
             trace_step()
-        args.no_cpu = True
 
-    # A GPU that has been idle runs its first half second of work below its clocks (3 % on this frame).  Whatever
+    # A GPU that has been idle runs its first half second of work below its clocks (3 % on the demo frame).  Whatever
     # warm-up count was asked for, the device is first kept busy for about that long, the same number of steps on
     # every rank (the steps contain a collective).
     prewarm = 0
-    if not args.no_prewarm:
-        def agreed(seconds):                       # the slowest rank's clock, so that every rank runs the same steps
-            if world_size == 1:
-                return seconds
-            t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return float(t.item())
+    if prewarm_enabled:
         t_warm = time.perf_counter()
         step()
         torch.cuda.synchronize()
         prewarm = 1
-        chunk = max(1, min(64, int(0.1 / max(agreed(time.perf_counter() - t_warm), 1e-6))))
-        while agreed(time.perf_counter() - t_warm) < 0.6:
+        chunk = max(1, min(64, int(0.1 / max(env.max_over_ranks(time.perf_counter() - t_warm), 1e-6))))
+        while env.max_over_ranks(time.perf_counter() - t_warm) < 0.6:
             for _ in range(chunk):
                 step()
             torch.cuda.synchronize()
             prewarm += chunk
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     r.sync()
@@ -245,7 +273,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
     if world_size > 1:
@@ -254,15 +282,83 @@ def main():
     dt = time.perf_counter() - t0
     r.sync()                                   # folds the HIP events of the K launches into the statistics
     kstats = r.stats()
+    return {"world": world, "objs": objs, "kw": kw, "st": st, "r": r, "stats": stats, "kstats": kstats, "prewarm": prewarm,
+            "progressive": progressive,
+            "dt": env.max_over_ranks(dt), "paths": env.max_over_ranks(stats.paths, "sum"), "kernel_ms": env.max_over_ranks(kstats.dominant_kernel_ms)}
 
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    p = torch.tensor([float(stats.paths)], dtype=torch.float64, device="cuda")
-    k = torch.tensor([float(kstats.dominant_kernel_ms)], dtype=torch.float64, device="cuda")
-    if world_size > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(p, op=dist.ReduceOp.SUM)
-        dist.all_reduce(k, op=dist.ReduceOp.MAX)
-    dt, total_paths, kernel_ms = float(t.item()), float(p.item()), float(k.item())
+
+def roofline_block(name, m, world_size, flops_per_path=None):
+    """fp32 VALU roofline of pt_k_trace for one measurement: neither HBM (0.03 TB/s moved) nor MFMA (no dense contraction
+    in a path tracer) bounds this kernel, the vector ALUs' instruction issue does, so the peak quoted is the vector fp32 peak."""
+    k = m["kstats"]
+    roof = {"bound": "valu", "kernel": "pt_k_trace", "achieved": None, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+            "frac": None, "traffic": None, "kernel_ms": m["kernel_ms"],
+            "kernel_ms_min": float(k.trace_ms_min), "kernel_ms_max": float(k.trace_ms_max)}
+    if flops_per_path is None:
+        flops_per_path = KNOWN_FLOPS_PER_PATH.get(name)
+    if flops_per_path is not None and m["kernel_ms"] > 0:
+        roof["flops_per_path"] = flops_per_path
+        roof["achieved"] = flops_per_path * m["paths"] / world_size / (m["kernel_ms"] * 1e-3) / 1e12
+        roof["frac"] = roof["achieved"] / PEAK_FP32_VALU_TFLOPS
+        roof["frac_of_scalar_issue_peak"] = roof["achieved"] / PEAK_SCALAR_ISSUE_TFLOPS
+    return roof
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--workload", default="demo-1080p-64spp-d8")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed steps that bring an idle GPU up to its clocks")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the two grid-scene configurations that follow the default workload")
+    ap.add_argument("--ranges", type=int, default=0, help="pt_settings.sample_ranges (0 = the library's choice)")
+    args = ap.parse_args()
+
+    env = Env(args.gpus)
+    torch, dist, world_size, rank = env.torch, env.dist, env.world_size, env.rank
+    m = measure(env, args.workload, args.steps, args.warmup, not args.no_prewarm, args.ranges)
+    world, objs, kw, st, r, stats, kstats, prewarm = m["world"], m["objs"], m["kw"], m["st"], m["r"], m["stats"], m["kstats"], m["prewarm"]
+    dt, total_paths, kernel_ms = m["dt"], m["paths"], m["kernel_ms"]
+    if m["progressive"]:
+        args.no_cpu = True
+
+    # The application's view of the same frame (one GPU only): pt_render_start with host pointers in -> done with the
+    # image in the caller's host buffer, i.e. set-up, upload, every kernel and the download.  Median of a few shots into
+    # a pageable buffer the caller keeps between renders (the reference's malloc'ed AppData::buffer) and into one from
+    # pt_image_alloc (page-locked).  The first shot of a context builds the random tables and is not counted.
+    end_to_end = None
+    if world_size == 1 and kw.get("frame_index", -1) < 0:
+        shots = 9 if ms_hint(dt, args.steps) < 50 else 3
+        end_to_end = {"definition": "pt_render_start -> done, host scene in, host image out"}
+        for label, image in (("pageable", np.zeros((st.height, st.width, 3), np.float32)), ("pinned", r.image_alloc(st.width, st.height))):
+            times = []
+            for shot in range(shots + 1):
+                ts = time.perf_counter()
+                r.start(world, objs, st, out=image)
+                r.wait()
+                times.append((time.perf_counter() - ts) * 1e3)
+            times = sorted(times[1:])
+            end_to_end[f"ms_{label}"] = times[len(times) // 2]
+            end_to_end[f"mpaths_per_s_{label}"] = stats.paths / times[len(times) // 2] / 1e3
+            if label == "pinned":
+                r.image_free(image)
+        end_to_end["shots"] = shots
+
+    # The grid-scene configurations beside the headline one, a few frames each (same partitioning, same pipeline): the
+    # glass scene (1080p, 128 spp, depth 32, lens) and the 100 000-entity scene (3840x2160, 256 spp) - the frame that
+    # is long enough to scale over eight GPUs.  Only after the default workload; every rank takes part.
+    secondary = []
+    if args.workload == "demo-1080p-64spp-d8" and not args.no_secondary:
+        r.close()
+        r = None
+        for name, k_steps, k_warm in (("glass-1080p-128spp-d32", 10, 2), ("dense100k-4k-256spp-d8", 3, 1)):
+            mm = measure(env, name, k_steps, k_warm, False, 0)
+            secondary.append({"workload": name, "steps": k_steps, "warmup": k_warm, "ms_per_step": mm["dt"] / k_steps * 1e3,
+                              "value": mm["paths"] * k_steps / mm["dt"] / 1e6, "unit": "Mpaths/s", "paths_per_frame": int(mm["paths"]),
+                              "objects": len(mm["objs"]), "roofline": roofline_block(name, mm, world_size)})
+            mm["r"].close()
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -278,39 +374,32 @@ def main():
                        "rays_per_frame_rank0": int(kstats.rays), "partition": f"8x8 tiles round-robin over {world_size} GPU(s)",
                        "seed_policy": "per-sample PCG32 streams"},
         }
-        # neither HBM (0.03 TB/s moved) nor MFMA (no dense contraction in a path tracer) bounds this kernel: the
-        # fp32 vector ALUs' instruction issue does, so the peak quoted is the vector fp32 peak
-        roof = {"bound": "valu", "kernel": "pt_k_trace", "achieved": None, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                "frac": None, "traffic": None, "kernel_ms": kernel_ms,
-                "kernel_ms_min": float(kstats.trace_ms_min), "kernel_ms_max": float(kstats.trace_ms_max)}
+        flops_per_path = None
         if not args.no_cpu and world_size == 1:          # the CPU leg belongs to the one-GPU line only
             base, counters, base_paths = cpu_baseline(world, objs, kw)
             out["cpu_baseline"] = base
             flops_per_path = flops_from_counters(counters) / max(1, counters["paths"])
-            flops_per_launch = flops_per_path * total_paths / world_size
-            roof["flops_per_path"] = flops_per_path
-            roof["achieved"] = flops_per_launch / (kernel_ms * 1e-3) / 1e12
-        elif args.workload in KNOWN_FLOPS_PER_PATH:
-            roof["flops_per_path"] = KNOWN_FLOPS_PER_PATH[args.workload]
-            roof["achieved"] = roof["flops_per_path"] * total_paths / world_size / (kernel_ms * 1e-3) / 1e12
-        if roof["achieved"] is not None:
-            roof["frac"] = roof["achieved"] / PEAK_FP32_VALU_TFLOPS
-            roof["frac_of_scalar_issue_peak"] = roof["achieved"] / PEAK_SCALAR_ISSUE_TFLOPS
+        roof = roofline_block(args.workload, m, world_size, flops_per_path)
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
-                m = json.load(open(pmc))
-                if m.get("workload") == args.workload and m.get("n_gpus", 1) == world_size:
-                    roof["traffic"] = m.get("hbm_bytes_per_launch")
-                    roof["traffic_source"] = m.get("source")
+                pm = json.load(open(pmc))
+                if pm.get("workload") == args.workload and pm.get("n_gpus", 1) == world_size:
+                    roof["traffic"] = pm.get("hbm_bytes_per_launch")
+                    roof["traffic_source"] = pm.get("source")
             except Exception:
                 pass
         out["roofline"] = roof
+        if end_to_end is not None:
+            out["end_to_end"] = end_to_end
+        if secondary:
+            out["secondary"] = secondary
         # algorithmic HBM bytes of the trace kernel: one 16-byte range sum per pixel and range, written once
         # (pt_k_resolve then reads them and writes the 12-byte pixels)
         out["hbm_algorithmic_bytes_per_launch"] = int(16 * stats.pixels * api.load_core().pt_sample_ranges(C.byref(st)))
         print(json.dumps(out), flush=True)
-    r.close()
+    if r is not None:
+        r.close()
     if world_size > 1:
         dist.destroy_process_group()
 

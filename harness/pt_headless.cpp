@@ -7,8 +7,9 @@
 //               [--seed N] [--gpus 0,1,...] [--out IMAGE.ppm] [--pfm IMAGE.pfm] [--poll-ms N]
 //               [--abort-after SECONDS] [--quiet]
 //
-// With several GPUs every device gets its own context and a round-robin share of the image's 8x8
-// tiles; all contexts fill the one caller-owned image.  Prints one JSON line with the metrics the
+// With several GPUs (--gpus 0,1,...; an ordinal may repeat) the frame goes through the pt_group_* calls: every
+// entry gets a context and a round-robin share of the image's 8x8 tiles, the shares are gathered device to device
+// on the first GPU, assembled there and copied out once.  Prints one JSON line with the metrics the
 // reference shows in its stats panel (code/app.cpp:2879-2896): pixels, samples, time, plus Mpaths/s.
 #include <chrono>
 #include <cmath>
@@ -79,58 +80,43 @@ int main(int argc, char** argv) {
 	}
 
 	const int parts = (int)gpus.size();
-	std::vector<pt_ctx*> ctx((size_t)parts, nullptr);
-	for(int p = 0; p < parts; p++) {
-		ctx[(size_t)p] = pt_create(gpus[(size_t)p]);
-		if(!ctx[(size_t)p]) { fprintf(stderr, "pt_create(%d): %s\n", gpus[(size_t)p], pt_last_error(nullptr)); return 1; }
-	}
+	pt_group* group = pt_group_create(gpus.data(), parts);
+	if(!group) { fprintf(stderr, "pt_group_create: %s\n", pt_last_error(nullptr)); return 1; }
 	std::vector<float> image((size_t)st.width * st.height * 3, 0.0f);
 
 	auto t0 = std::chrono::steady_clock::now();
-	for(int p = 0; p < parts; p++) {
-		pt_settings s = st;
-		s.part_index = p;
-		s.part_count = parts;
-		int rc = pt_render_start(ctx[(size_t)p], &world, objects.data(), (int)objects.size(), &s, image.data());
-		if(rc != PT_OK) { fprintf(stderr, "pt_render_start: %s\n", pt_last_error(ctx[(size_t)p])); return 1; }
+	if(pt_group_render_start(group, &world, objects.data(), (int)objects.size(), &st, image.data()) != PT_OK) {
+		fprintf(stderr, "pt_group_render_start: %s\n", pt_group_last_error(group));
+		return 1;
 	}
 	// the application's frame loop: poll once per frame, abort on request
 	bool aborted = false;
 	for(;;) {
-		bool all_done = true;
-		float fraction = 0;
-		for(int p = 0; p < parts; p++) {
-			pt_progress info;
-			int rc = pt_render_progress(ctx[(size_t)p], &info);
-			if(rc != PT_OK) { fprintf(stderr, "render failed: %s\n", pt_last_error(ctx[(size_t)p])); return 1; }
-			all_done = all_done && info.done;
-			fraction += info.fraction / parts;
-		}
+		pt_progress info;
+		if(pt_group_render_progress(group, &info) != PT_OK) { fprintf(stderr, "render failed: %s\n", pt_group_last_error(group)); return 1; }
 		double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-		if(!quiet) fprintf(stderr, "\r%5.1f %%  %.3f s", fraction * 100, elapsed);
-		if(all_done) break;
+		if(!quiet) fprintf(stderr, "\r%5.1f %%  %.3f s", info.fraction * 100, elapsed);
+		if(info.done) break;
 		if(abort_after >= 0 && !aborted && elapsed >= abort_after) {
-			for(int p = 0; p < parts; p++) pt_render_abort(ctx[(size_t)p]);
+			pt_group_render_abort(group);
 			aborted = true;
 		}
 		std::this_thread::sleep_for(std::chrono::milliseconds(poll_ms));
 	}
 	if(!quiet) fprintf(stderr, "\n");
+	if(pt_group_render_wait(group) != PT_OK) { fprintf(stderr, "render failed: %s\n", pt_group_last_error(group)); return 1; }
+	pt_progress info;
+	pt_group_render_progress(group, &info);
 	unsigned long long paths = 0, rays = 0, pixels = 0;
-	double seconds = 0, kernel_ms = 0;
-	int was_aborted = 0;
+	double seconds = info.seconds, kernel_ms = 0;
+	int was_aborted = info.aborted;
 	for(int p = 0; p < parts; p++) {
-		int rc = pt_render_wait(ctx[(size_t)p]);
-		if(rc != PT_OK) { fprintf(stderr, "render failed: %s\n", pt_last_error(ctx[(size_t)p])); return 1; }
-		pt_progress info;
-		pt_render_progress(ctx[(size_t)p], &info);
 		pt_stats stats;
-		pt_get_stats(ctx[(size_t)p], &stats);
+		pt_get_stats(pt_group_ctx(group, p), &stats);
 		paths += stats.paths; rays += stats.rays; pixels += stats.pixels;
-		seconds = info.seconds > seconds ? info.seconds : seconds;
 		kernel_ms = stats.trace_ms > kernel_ms ? stats.trace_ms : kernel_ms;
-		was_aborted |= info.aborted;
 	}
+	if(was_aborted) paths = info.paths_done;
 
 	if(!out_ppm.empty()) {
 		FILE* f = fopen(out_ppm.c_str(), "wb");
@@ -138,7 +124,8 @@ int main(int argc, char** argv) {
 		fprintf(f, "P6\n%d %d\n255\n", st.width, st.height);
 		std::vector<unsigned char> bytes(image.size());
 		if(parts == 1 && !was_aborted) {
-			if(pt_present_srgb8(ctx[0], bytes.data()) != PT_OK) { fprintf(stderr, "pt_present_srgb8: %s\n", pt_last_error(ctx[0])); return 1; }
+			pt_ctx* only = pt_group_ctx(group, 0);
+			if(pt_present_srgb8(only, bytes.data()) != PT_OK) { fprintf(stderr, "pt_present_srgb8: %s\n", pt_last_error(only)); return 1; }
 		} else {
 			for(size_t i = 0; i < image.size(); i++) bytes[i] = encode_srgb8(image[i]);
 		}
@@ -156,6 +143,6 @@ int main(int argc, char** argv) {
 	       "\"pixels\": %llu, \"paths\": %llu, \"rays\": %llu, \"seconds\": %.6f, \"kernel_ms\": %.3f, \"mpaths_per_s\": %.1f, \"aborted\": %d}\n",
 	       scene.c_str(), st.width, st.height, st.spp_wanted, st.max_bounces, (int)objects.size(), parts, pixels, paths, rays, seconds,
 	       kernel_ms, seconds > 0 ? paths / seconds / 1e6 : 0.0, was_aborted);
-	for(int p = 0; p < parts; p++) pt_destroy(ctx[(size_t)p]);
+	pt_group_destroy(group);
 	return 0;
 }

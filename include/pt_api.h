@@ -153,6 +153,12 @@ int pt_default_scene(pt_world* world, pt_object* objects, int capacity, int* cou
 int pt_render_start(pt_ctx* ctx, const pt_world* world, const pt_object* objects, int n_objects,
                     const pt_settings* settings, float* rgb);
 
+/* Optional replacement of the image allocation code/app.cpp:1156-1159: width*height*3 floats of page-locked host
+ * memory.  Any host buffer works as `rgb`; into one from here the finished image is copied by the copy engine at
+ * the speed of the bus (0.5 ms for 1080p), into pageable memory through a staging image and host threads. */
+float* pt_image_alloc(pt_ctx* ctx, int width, int height);
+void pt_image_free(pt_ctx* ctx, float* image);
+
 /* Replaces the per-frame poll code/app.cpp:1436-1440 (threadQueueFinished + processTime). */
 int pt_render_progress(pt_ctx* ctx, pt_progress* info);
 
@@ -276,6 +282,29 @@ int pt_partition_floats(const pt_ctx* ctx, size_t* floats);
 int pt_partition_tiles(int width, int height, int part_index, int part_count);
 int pt_assemble(pt_ctx* ctx, const float* d_parts, size_t stride_floats, int part_count, int width,
                 int height, float* d_rgb, void* hip_stream);
+
+/*
+ * The same frame on several GPUs driven by one process (the reference's counterpart is its pool of worker
+ * threads filling one AppData::buffer, code/app.cpp:1359-1419, code/raycast.cpp:1270).  A group holds one
+ * context per entry of `devices` (an ordinal may repeat: several partitions on one GPU); partition p renders
+ * the tiles t with t % n == p.  When the partitions are done their tile buffers are copied device to device
+ * into the first device's gathered buffer (hipMemcpyPeerAsync: over xGMI between different GPUs, every peer on
+ * its own link), laid out there as the image (pt_assemble's kernel) and copied to `rgb` once.  The image is
+ * bit-identical to the one-GPU image for any n.  start / progress / abort / wait behave like their
+ * pt_render_* namesakes; settings->part_index / part_count are ignored.  pt_group_ctx gives the context of a
+ * partition for pt_get_stats / pt_last_error (not for rendering while the group is active).
+ */
+typedef struct pt_group pt_group;
+pt_group* pt_group_create(const int* devices, int n);
+void pt_group_destroy(pt_group* group);
+int pt_group_size(const pt_group* group);
+pt_ctx* pt_group_ctx(pt_group* group, int part);
+const char* pt_group_last_error(const pt_group* group);
+int pt_group_render_start(pt_group* group, const pt_world* world, const pt_object* objects, int n_objects,
+                          const pt_settings* settings, float* rgb);
+int pt_group_render_progress(pt_group* group, pt_progress* info);
+int pt_group_render_abort(pt_group* group);
+int pt_group_render_wait(pt_group* group);
 
 /* Scene files in the reference's own format (saveScene / loadScene, code/raycast.cpp:1578-1604):
  * a 224-byte World image followed by 172-byte Object images.  pt_scene_load with objects == NULL

@@ -158,6 +158,22 @@ def load_core():
     lib.pt_debug_primary.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
     lib.pt_cast_rays.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
                                  C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.pt_group_create.restype = C.c_void_p
+    lib.pt_group_create.argtypes = [C.POINTER(C.c_int), C.c_int]
+    lib.pt_group_destroy.argtypes = [C.c_void_p]
+    lib.pt_group_size.argtypes = [C.c_void_p]
+    lib.pt_group_ctx.restype = C.c_void_p
+    lib.pt_group_ctx.argtypes = [C.c_void_p, C.c_int]
+    lib.pt_group_last_error.restype = C.c_char_p
+    lib.pt_group_last_error.argtypes = [C.c_void_p]
+    lib.pt_group_render_start.argtypes = [C.c_void_p, C.POINTER(pt_world), C.POINTER(pt_object), C.c_int,
+                                          C.POINTER(pt_settings), C.POINTER(C.c_float)]
+    lib.pt_group_render_progress.argtypes = [C.c_void_p, C.POINTER(pt_progress)]
+    lib.pt_group_render_abort.argtypes = [C.c_void_p]
+    lib.pt_group_render_wait.argtypes = [C.c_void_p]
+    lib.pt_image_alloc.restype = C.POINTER(C.c_float)
+    lib.pt_image_alloc.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.pt_image_free.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.pt_pick_rays.argtypes = lib.pt_cast_rays.argtypes
     lib.pt_cast_rays_noalloc.argtypes = lib.pt_cast_rays.argtypes
     lib.pt_render_snapshot.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
@@ -226,6 +242,19 @@ class Renderer:
         self._check(self.lib.pt_render_start(self.ctx, C.byref(world), self._objs, len(objs), C.byref(settings),
                                              fptr(self._out)), "pt_render_start")
         return self._out
+
+    def image_alloc(self, width, height):
+        """A page-locked (height, width, 3) float image owned by the library; release it with image_free."""
+        p = self.lib.pt_image_alloc(self.ctx, width, height)
+        if not p:
+            raise PtError("pt_image_alloc failed: " + self.lib.pt_last_error(self.ctx).decode())
+        a = np.ctypeslib.as_array(p, shape=(height, width, 3))
+        self._images = getattr(self, "_images", {})
+        self._images[a.ctypes.data] = p
+        return a
+
+    def image_free(self, a):
+        self.lib.pt_image_free(self.ctx, self._images.pop(a.ctypes.data))
 
     def progress(self):
         p = pt_progress()
@@ -348,6 +377,56 @@ class Renderer:
         hist = np.zeros(256, np.uint64)
         self._check(self.lib.pt_debug_srgb8_sweep(self.ctx, first_bits, count, C.byref(bad), u64ptr(hist)), "pt_debug_srgb8_sweep")
         return bad.value, hist
+
+
+class Group:
+    """Mirror of the pt_group_* calls: one frame on several GPUs (or several partitions of one GPU) of this process."""
+
+    def __init__(self, devices):
+        self.lib = load_core()
+        arr = (C.c_int * len(devices))(*devices)
+        self.g = self.lib.pt_group_create(arr, len(devices))
+        if not self.g:
+            raise PtError("pt_group_create failed: " + self.lib.pt_last_error(None).decode())
+
+    def close(self):
+        if self.g:
+            self.lib.pt_group_destroy(self.g)
+            self.g = None
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise PtError(f"{what} failed ({rc}): {self.lib.pt_group_last_error(self.g).decode()}")
+
+    def start(self, world, objs, settings, out=None):
+        self._objs = object_array(objs)
+        self._out = out if out is not None else np.zeros((settings.height, settings.width, 3), np.float32)
+        self._check(self.lib.pt_group_render_start(self.g, C.byref(world), self._objs, len(objs), C.byref(settings), fptr(self._out)),
+                    "pt_group_render_start")
+        return self._out
+
+    def progress(self):
+        p = pt_progress()
+        self._check(self.lib.pt_group_render_progress(self.g, C.byref(p)), "pt_group_render_progress")
+        return p
+
+    def abort(self):
+        self._check(self.lib.pt_group_render_abort(self.g), "pt_group_render_abort")
+
+    def wait(self):
+        self._check(self.lib.pt_group_render_wait(self.g), "pt_group_render_wait")
+        return self._out
+
+    def render(self, world, objs, settings, out=None):
+        self.start(world, objs, settings, out)
+        return self.wait()
+
+    def part_stats(self, part):
+        st = pt_stats()
+        rc = self.lib.pt_get_stats(self.lib.pt_group_ctx(self.g, part), C.byref(st))
+        if rc != 0:
+            raise PtError(f"pt_get_stats failed ({rc})")
+        return st
 
 
 def srgb8_thresholds():

@@ -61,6 +61,9 @@ struct pt_ctx {
 	DevBuf geo, cell_start, cell_items, cell_entries, obj_range, partial, fracs, bbox, grid_cursor, grid_sums, tile_cost, tile_order, dirs, disc, samples, offsets, frame_dev, fb, accum, counter, stats_dev, scratch;
 	DevBuf thresholds;                   // the screenshot encoder's table
 	bool thresholds_ready = false;
+	void* dl_host = nullptr;             // pinned staging image of downloads into pageable memory
+	size_t dl_host_bytes = 0;
+	hipEvent_t dl_event[8] = {};
 	void* snap_host = nullptr;           // pinned landing area of snapshots: two halves that take turns (poll thread only)
 	hipEvent_t snap_event[2] = { nullptr, nullptr };
 	ptl::TraceCaps caps{};               // compute units and resident workgroups per unit, of this context's device
@@ -103,6 +106,23 @@ struct pt_ctx {
 	std::chrono::steady_clock::time_point t_start, t_end;
 	float* user_rgb = nullptr;
 	float fraction_shown = 0;            // poll thread: the largest fraction reported for the active render
+};
+
+
+// One frame on several GPUs of one process: a context per partition, the partitions' tile buffers copied device to
+// device into the root's gathered buffer, assembled there and downloaded once.
+struct pt_group {
+	std::vector<pt_ctx*> part;
+	std::string err;
+	std::mutex mu;
+	pt_settings st{};
+	float* user_rgb = nullptr;
+	DevBuf gathered, image;              // on the root's device (part[0]): partitions side by side, the assembled image
+	std::thread worker;
+	std::atomic<int> active{ 0 }, done{ 0 }, aborted{ 0 }, status{ 0 }, abort_requested{ 0 };
+	std::atomic<uint64_t> done_pixels{ 0 }, done_paths{ 0 };
+	uint64_t total_pixels = 0, total_paths = 0;
+	std::chrono::steady_clock::time_point t_start, t_end;
 };
 
 namespace {
@@ -605,15 +625,61 @@ void place_pixels(const pt_ctx* c, const float* src, const uint8_t* mask, float*
 	if(paths) *paths = n_paths;
 }
 
+// A whole image on the context's device to the caller.  Into pinned memory (pt_image_alloc, or a buffer the worker managed to pin) the copy
+// engine writes directly, at the speed of the bus.  Into pageable memory the runtime's own copy is one thread moving
+// bytes out of its staging buffers (17 GB/s measured); here the copy engine fills a pinned staging image of the
+// context in segments and a few threads move each segment on as soon as it has landed.
+int download_image(pt_ctx* c, const void* d_image, size_t bytes, float* rgb) {
+	hipPointerAttribute_t attr;
+	bool direct = bytes < (4u << 20);
+	if(!direct) {
+		direct = hipPointerGetAttributes(&attr, rgb) == hipSuccess && attr.type == hipMemoryTypeHost;
+		(void)hipGetLastError();             // an ordinary malloc'ed pointer is reported as an error: that is the answer, not a failure
+	}
+	static const int threads_wanted = getenv("PT_DOWNLOAD_THREADS") ? atoi(getenv("PT_DOWNLOAD_THREADS")) : 4;
+	if(direct || threads_wanted < 1) {
+		PT_HIP(c, hipMemcpyAsync(rgb, d_image, bytes, hipMemcpyDeviceToHost, c->stream));
+		PT_HIP(c, hipStreamSynchronize(c->stream));
+		return PT_OK;
+	}
+	if(c->dl_host_bytes < bytes) {
+		if(c->dl_host) { (void)hipHostFree(c->dl_host); c->dl_host = nullptr; c->dl_host_bytes = 0; }
+		PT_HIP(c, hipHostMalloc(&c->dl_host, bytes, hipHostMallocDefault));
+		c->dl_host_bytes = bytes;
+	}
+	constexpr int kSegments = 8;
+	for(hipEvent_t& e : c->dl_event) if(!e) PT_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	const size_t seg = ((bytes / kSegments) + 4095) & ~(size_t)4095;
+	auto span = [&](int k, size_t* at, size_t* len) { *at = std::min(bytes, (size_t)k * seg); *len = std::min(seg, bytes - *at); };
+	for(int k = 0; k < kSegments; k++) {
+		size_t at, len;
+		span(k, &at, &len);
+		if(len) PT_HIP(c, hipMemcpyAsync((char*)c->dl_host + at, (const char*)d_image + at, len, hipMemcpyDeviceToHost, c->stream));
+		PT_HIP(c, hipEventRecord(c->dl_event[k], c->stream));
+	}
+	const int n_threads = std::min(threads_wanted, kSegments);
+	std::atomic<int> failed{ 0 };
+	auto mover = [&](int t) {
+		for(int k = t; k < kSegments; k += n_threads) {
+			size_t at, len;
+			span(k, &at, &len);
+			if(hipEventSynchronize(c->dl_event[k]) != hipSuccess) { failed.store(1); return; }
+			if(len) memcpy((char*)rgb + at, (const char*)c->dl_host + at, len);
+		}
+	};
+	std::vector<std::thread> helpers;
+	for(int t = 1; t < n_threads; t++) helpers.emplace_back(mover, t);
+	mover(0);
+	for(std::thread& h : helpers) h.join();
+	if(failed.load()) return fail(c, PT_ERR_DEVICE, "waiting for the image copy failed: %s", hipGetErrorString(hipGetLastError()));
+	return PT_OK;
+}
+
 int download(pt_ctx* c, float* rgb) {
 	if(!c->prepared) return fail(c, PT_ERR_STATE, "pt_download before pt_prepare");
 	if(!rgb) return fail(c, PT_ERR_ARG, "null output");
 	const pt_settings& s = c->st;
-	if(s.part_count == 1) {
-		PT_HIP(c, hipMemcpyAsync(rgb, c->fb.p, c->fb_floats * 4, hipMemcpyDeviceToHost, c->stream));
-		PT_HIP(c, hipStreamSynchronize(c->stream));
-		return PT_OK;
-	}
+	if(s.part_count == 1) return download_image(c, c->fb.p, c->fb_floats * 4, rgb);
 	// tile-major partition buffer -> the caller's row-major image; other partitions' pixels are left alone
 	std::vector<float> tmp(c->fb_floats);
 	PT_HIP(c, hipMemcpyAsync(tmp.data(), c->fb.p, c->fb_floats * 4, hipMemcpyDeviceToHost, c->stream));
@@ -643,24 +709,42 @@ int download_finished(pt_ctx* c, float* rgb, uint64_t* pixels, uint64_t* paths) 
 
 void worker_main(pt_ctx* c) {
 	int rc = PT_OK;
+	static const bool times = getenv("PT_DEBUG_TIMES") != nullptr;      // phase times of an asynchronous render on stderr
+	auto t0 = std::chrono::steady_clock::now();
+	auto lap = [&](const char* what) {
+		if(!times) return;
+		auto t1 = std::chrono::steady_clock::now();
+		fprintf(stderr, "  %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+		t0 = t1;
+	};
+	if(times) fprintf(stderr, "render: thread start %.3f ms\n", std::chrono::duration<double, std::milli>(t0 - c->t_start).count());
 	if(hipSetDevice(c->device) != hipSuccess) rc = fail(c, PT_ERR_DEVICE, "hipSetDevice(%d) failed", c->device);
 	if(rc == PT_OK) rc = prepare(c);
+	lap("prepare");
 	if(rc == PT_OK) rc = trace(c, nullptr, nullptr, false, true);
+	lap("launch");
 	// While the device traces, the caller's image is pinned so that the copy at the end runs at the speed of the
 	// bus: a copy into pageable memory goes through the runtime's staging buffers at a fifth of that (2.3 ms of a
 	// 4.3 ms 1080p frame).  Worth it from a megabyte up; where pinning fails the pageable copy is used.
 	const size_t bytes = (size_t)c->st.width * (size_t)c->st.height * 12;
 	bool pinned = false;
 	if(rc == PT_OK && c->st.part_count == 1 && bytes >= (1u << 20) && getenv("PT_NO_PIN") == nullptr) {
-		pinned = hipHostRegister(c->user_rgb, bytes, hipHostRegisterDefault) == hipSuccess;
+		hipError_t pe = hipHostRegister(c->user_rgb, bytes, hipHostRegisterDefault);
+		pinned = pe == hipSuccess;
+		if(times) fprintf(stderr, "  hipHostRegister: %s\n", hipGetErrorString(pe));
 		if(!pinned) (void)hipGetLastError();
 	}
+	lap("pin");
 	if(rc == PT_OK) rc = wait_launches(c);
+	lap("wait");
 	if(rc == PT_OK) rc = collect(c);
+	lap("collect");
 	const bool aborted = *c->abort_flag != 0;
 	uint64_t pixels = c->stats.pixels, paths = c->stats.paths;
 	if(rc == PT_OK) rc = aborted ? download_finished(c, c->user_rgb, &pixels, &paths) : download(c, c->user_rgb);
+	lap("download");
 	if(pinned && hipHostUnregister(c->user_rgb) != hipSuccess) (void)hipGetLastError();
+	lap("unpin");
 	c->done_pixels.store(rc == PT_OK ? pixels : 0);
 	c->done_paths.store(rc == PT_OK ? paths : 0);
 	c->aborted.store(aborted ? 1 : 0);
@@ -715,6 +799,8 @@ void pt_destroy(pt_ctx* c) {
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 	if(c->side) (void)hipStreamDestroy(c->side);
 	for(hipEvent_t e : c->snap_event) if(e) (void)hipEventDestroy(e);
+	for(hipEvent_t e : c->dl_event) if(e) (void)hipEventDestroy(e);
+	if(c->dl_host) (void)hipHostFree(c->dl_host);
 	delete c;
 }
 
@@ -840,6 +926,41 @@ int pt_render_start(pt_ctx* c, const pt_world* w, const pt_object* objs, int n, 
 	return PT_OK;
 }
 
+// Work groups handed out so far, as a share: the trace kernel writes the number into a pinned host word every 64th
+// group fetch, so a poll is one load.  (Nothing that runs on the device can be used for this: beside the persistent
+// trace kernel no kernel starts before the frame ends, and the runtime copies a few bytes with a kernel.)
+static void live_fraction(pt_ctx* c, float* fraction, uint64_t* paths_done) {
+	int n_groups = 0;
+	uint64_t paths = 0;
+	{
+		std::lock_guard<std::mutex> l(c->mu);
+		if(c->live_valid) { n_groups = c->live_job.n_groups; paths = c->live_paths; }
+	}
+	if(n_groups <= 0) { *fraction = 0; *paths_done = 0; return; }
+	const uint32_t got = *(volatile uint32_t*)c->progress_word;
+	float f = (float)got / (float)n_groups;
+	f = f > 1 ? 1 : f;
+	if(f < c->fraction_shown) f = c->fraction_shown;         // wavefronts write in any order: never step back
+	c->fraction_shown = f;
+	*fraction = f;
+	*paths_done = (uint64_t)((double)paths * f);
+}
+
+float* pt_image_alloc(pt_ctx* c, int width, int height) {
+	if(!c) return nullptr;
+	if(width < 1 || height < 1 || width > 16384 || height > 16384) { fail(c, PT_ERR_LIMIT, "image size %dx%d outside 1..16384", width, height); return nullptr; }
+	if(hipSetDevice(c->device) != hipSuccess) { fail(c, PT_ERR_DEVICE, "hipSetDevice(%d) failed", c->device); return nullptr; }
+	void* p = nullptr;
+	hipError_t e = hipHostMalloc(&p, (size_t)width * (size_t)height * 12, hipHostMallocDefault);
+	if(e != hipSuccess) { fail(c, PT_ERR_NOMEM, "hipHostMalloc: %s", hipGetErrorString(e)); return nullptr; }
+	return (float*)p;
+}
+
+void pt_image_free(pt_ctx* c, float* image) {
+	(void)c;
+	if(image) (void)hipHostFree(image);
+}
+
 int pt_render_progress(pt_ctx* c, pt_progress* info) {
 	if(!c || !info) return PT_ERR_ARG;
 	memset(info, 0, sizeof *info);
@@ -855,24 +976,7 @@ int pt_render_progress(pt_ctx* c, pt_progress* info) {
 		return c->status.load();
 	}
 	info->seconds = std::chrono::duration<double>(now - c->t_start).count();
-	// Work groups handed out so far: the trace kernel writes the number into a pinned host word every 64th group
-	// fetch, so a poll is one load.  (Nothing that runs on the device can be used for this: beside the persistent trace
-	// kernel no kernel starts before the frame ends, and the runtime copies a few bytes with a kernel.)
-	int n_groups = 0;
-	uint64_t paths = 0;
-	{
-		std::lock_guard<std::mutex> l(c->mu);
-		if(c->live_valid) { n_groups = c->live_job.n_groups; paths = c->live_paths; }
-	}
-	if(n_groups > 0) {
-		const uint32_t got = *(volatile uint32_t*)c->progress_word;
-		float f = (float)got / (float)n_groups;
-		f = f > 1 ? 1 : f;
-		if(f < c->fraction_shown) f = c->fraction_shown;         // wavefronts write in any order: never step back
-		c->fraction_shown = f;
-		info->fraction = f;
-		info->paths_done = (uint64_t)((double)paths * f);
-	}
+	live_fraction(c, &info->fraction, &info->paths_done);
 	return PT_OK;
 }
 
@@ -967,6 +1071,235 @@ int pt_render_wait(pt_ctx* c) {
 	c->active.store(1);     // keep the finished render pollable until the next start
 	return c->status.load();
 }
+
+}  // extern "C"
+
+/* ---- several GPUs, one process ------------------------------------------------------------------- */
+
+namespace {
+
+int group_fail(pt_group* g, int code, const std::string& text) {
+	std::lock_guard<std::mutex> l(g->mu);
+	if(g->err.empty() || code != PT_OK) g->err = text;
+	return code;
+}
+
+// One partition: set-up, trace, then its tile buffer straight into the root's gathered buffer (device to device; over
+// xGMI when the two contexts sit on different GPUs).  After an abort request the partition delivers its finished pixels
+// through the host instead.  *gathered tells which way it went.
+int group_part(pt_group* g, int p, size_t stride_floats, bool* gathered) {
+	pt_ctx* c = g->part[(size_t)p];
+	pt_ctx* root = g->part[0];
+	const int n = (int)g->part.size();
+	*gathered = false;
+	if(hipSetDevice(c->device) != hipSuccess) return fail(c, PT_ERR_DEVICE, "hipSetDevice(%d) failed", c->device);
+	int rc = prepare(c);
+	if(rc == PT_OK) rc = trace(c, nullptr, nullptr, false, true);
+	if(rc == PT_OK) rc = wait_launches(c);
+	if(rc == PT_OK) rc = collect(c);
+	if(rc != PT_OK) return rc;
+	uint64_t pixels = c->stats.pixels, paths = c->stats.paths;
+	if(g->abort_requested.load()) {
+		rc = download_finished(c, g->user_rgb, &pixels, &paths);
+	} else if(n == 1) {
+		rc = download(c, g->user_rgb);
+	} else {
+		float* to = g->gathered.as<float>() + (size_t)p * stride_floats;
+		PT_HIP(c, hipMemcpyPeerAsync(to, root->device, c->fb.p, c->device, c->fb_floats * 4, c->stream));
+		PT_HIP(c, hipStreamSynchronize(c->stream));
+		*gathered = true;
+	}
+	if(rc == PT_OK) { g->done_pixels.fetch_add(pixels); g->done_paths.fetch_add(paths); }
+	return rc;
+}
+
+void group_main(pt_group* g) {
+	const int n = (int)g->part.size();
+	pt_ctx* root = g->part[0];
+	const pt_settings& s = g->st;
+	int rc = PT_OK;
+	size_t stride = 0;
+	for(int p = 0; p < n; p++) stride = std::max(stride, (size_t)pt_partition_tiles(s.width, s.height, p, n) * 192);
+	const size_t image_bytes = (size_t)s.width * (size_t)s.height * 12;
+	if(n > 1) {
+		hipError_t e = hipSetDevice(root->device);
+		if(e == hipSuccess) e = g->gathered.reserve((size_t)n * stride * 4);
+		if(e == hipSuccess) e = g->image.reserve(image_bytes);
+		if(e != hipSuccess) rc = group_fail(g, PT_ERR_DEVICE, std::string("gather buffers: ") + hipGetErrorString(e));
+	}
+	std::vector<int> rcs((size_t)n, PT_OK);
+	std::vector<char> went_by_device((size_t)n, 0);
+	if(rc == PT_OK) {
+		std::vector<std::thread> threads;
+		for(int p = 0; p < n; p++) threads.emplace_back([g, p, stride, &rcs, &went_by_device]() {
+			bool by_device = false;
+			rcs[(size_t)p] = group_part(g, p, stride, &by_device);
+			went_by_device[(size_t)p] = by_device ? 1 : 0;
+		});
+		for(std::thread& t : threads) t.join();
+		for(int p = 0; p < n && rc == PT_OK; p++)
+			if(rcs[(size_t)p] != PT_OK) rc = group_fail(g, rcs[(size_t)p], "partition " + std::to_string(p) + ": " + pt_last_error(g->part[(size_t)p]));
+	}
+	const bool aborted = g->abort_requested.load() != 0;
+	if(rc == PT_OK && n > 1) {
+		if(!aborted) {
+			// every partition is in the gathered buffer: lay them out as the image and copy it out once
+			if(hipSetDevice(root->device) != hipSuccess) rc = group_fail(g, PT_ERR_DEVICE, "hipSetDevice failed");
+			if(rc == PT_OK && ptl::launch_assemble(g->gathered.as<float>(), stride, n, s.width, s.height, g->image.as<float>(), root->stream) != hipSuccess)
+				rc = group_fail(g, PT_ERR_DEVICE, "pt_k_assemble launch failed");
+			if(rc == PT_OK && (rc = download_image(root, g->image.p, image_bytes, g->user_rgb)) != PT_OK) group_fail(g, rc, pt_last_error(root));
+		} else {
+			// the request came while some partitions had already gone to the gathered buffer: those are complete, and
+			// reach the caller's image through the host like the unfinished ones did
+			for(int p = 0; p < n && rc == PT_OK; p++) {
+				if(!went_by_device[(size_t)p]) continue;
+				pt_ctx* c = g->part[(size_t)p];
+				if(hipSetDevice(c->device) != hipSuccess) rc = group_fail(g, PT_ERR_DEVICE, "hipSetDevice failed");
+				else if((rc = download(c, g->user_rgb)) != PT_OK) group_fail(g, rc, pt_last_error(c));
+			}
+		}
+	}
+	g->aborted.store(aborted ? 1 : 0);
+	g->t_end = std::chrono::steady_clock::now();
+	g->status.store(rc);
+	g->done.store(1);
+}
+
+void group_join(pt_group* g) {
+	if(g->worker.joinable()) g->worker.join();
+	g->active.store(0);
+}
+
+}  // namespace
+
+extern "C" {
+
+pt_group* pt_group_create(const int* devices, int n) {
+	if(!devices || n < 1 || n > 64) { fail(nullptr, PT_ERR_ARG, "pt_group_create: 1..64 devices"); return nullptr; }
+	pt_group* g = new pt_group();
+	for(int p = 0; p < n; p++) {
+		pt_ctx* c = pt_create(devices[p]);
+		if(!c) { pt_group_destroy(g); return nullptr; }
+		g->part.push_back(c);
+	}
+	// direct access between the root and every other device, where the hardware offers it; without it the runtime
+	// stages the copies itself
+	const int root = devices[0];
+	for(int p = 1; p < n; p++) {
+		if(devices[p] == root) continue;
+		int can = 0;
+		if(hipDeviceCanAccessPeer(&can, devices[p], root) == hipSuccess && can && hipSetDevice(devices[p]) == hipSuccess) {
+			hipError_t e = hipDeviceEnablePeerAccess(root, 0);
+			if(e != hipSuccess) (void)hipGetLastError();      // already enabled counts as enabled
+		}
+	}
+	return g;
+}
+
+void pt_group_destroy(pt_group* g) {
+	if(!g) return;
+	if(g->active.load()) { pt_group_render_abort(g); group_join(g); }
+	if(!g->part.empty()) {
+		(void)hipSetDevice(g->part[0]->device);
+		g->gathered.release();
+		g->image.release();
+	}
+	for(pt_ctx* c : g->part) pt_destroy(c);
+	delete g;
+}
+
+int pt_group_size(const pt_group* g) { return g ? (int)g->part.size() : PT_ERR_ARG; }
+
+pt_ctx* pt_group_ctx(pt_group* g, int part) {
+	if(!g || part < 0 || part >= (int)g->part.size()) return nullptr;
+	return g->part[(size_t)part];
+}
+
+const char* pt_group_last_error(const pt_group* g) {
+	thread_local std::string text;
+	if(!g) return pt_last_error(nullptr);
+	{ std::lock_guard<std::mutex> l(const_cast<pt_group*>(g)->mu); text = g->err; }
+	return text.c_str();
+}
+
+int pt_group_render_start(pt_group* g, const pt_world* w, const pt_object* objs, int n_objects, const pt_settings* s, float* rgb) {
+	if(!g) return PT_ERR_ARG;
+	if(!rgb) return group_fail(g, PT_ERR_ARG, "null output buffer");
+	if(g->active.load() && !g->done.load()) return group_fail(g, PT_ERR_BUSY, "a render is already active");
+	if(g->active.load()) group_join(g);
+	const int n = (int)g->part.size();
+	if(!s) return group_fail(g, PT_ERR_ARG, "null settings");
+	for(int p = 0; p < n; p++) {
+		pt_ctx* c = g->part[(size_t)p];
+		if(c->active.load()) { if(!c->done.load()) return group_fail(g, PT_ERR_BUSY, "a partition's context is rendering on its own"); join_worker(c); }
+		pt_settings sp = *s;
+		sp.part_index = p;
+		sp.part_count = n;
+		int rc = store_inputs(c, w, objs, n_objects, &sp);
+		if(rc) return group_fail(g, rc, pt_last_error(c));
+		*c->abort_flag = 0;
+		*c->progress_word = 0;
+		c->fraction_shown = 0;
+		{ std::lock_guard<std::mutex> l(c->mu); c->live_valid = false; }
+	}
+	{ std::lock_guard<std::mutex> l(g->mu); g->err.clear(); }
+	g->st = *s;
+	g->user_rgb = rgb;
+	g->total_pixels = (uint64_t)s->width * (uint64_t)s->height;
+	g->done.store(0); g->aborted.store(0); g->status.store(0); g->abort_requested.store(0);
+	g->done_pixels.store(0); g->done_paths.store(0);
+	g->t_start = std::chrono::steady_clock::now();
+	g->active.store(1);
+	g->worker = std::thread(group_main, g);
+	return PT_OK;
+}
+
+int pt_group_render_progress(pt_group* g, pt_progress* info) {
+	if(!g || !info) return PT_ERR_ARG;
+	memset(info, 0, sizeof *info);
+	if(!g->active.load()) return group_fail(g, PT_ERR_STATE, "no render was started");
+	if(g->done.load()) {
+		info->done = 1;
+		info->aborted = g->aborted.load();
+		info->fraction = info->aborted ? (g->total_pixels ? (float)((double)g->done_pixels.load() / (double)g->total_pixels) : 0.0f) : 1.0f;
+		info->seconds = std::chrono::duration<double>(g->t_end - g->t_start).count();
+		info->paths_done = g->done_paths.load();
+		return g->status.load();
+	}
+	info->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - g->t_start).count();
+	double share = 0;
+	uint64_t paths = 0;
+	for(pt_ctx* c : g->part) {
+		float f = 0;
+		uint64_t done = 0;
+		live_fraction(c, &f, &done);
+		share += f;
+		paths += done;
+	}
+	info->fraction = (float)(share / (double)g->part.size());
+	info->paths_done = paths;
+	return PT_OK;
+}
+
+int pt_group_render_abort(pt_group* g) {
+	if(!g) return PT_ERR_ARG;
+	if(!g->active.load()) return group_fail(g, PT_ERR_STATE, "no render was started");
+	g->abort_requested.store(1);
+	for(pt_ctx* c : g->part) *c->abort_flag = 1;
+	return PT_OK;
+}
+
+int pt_group_render_wait(pt_group* g) {
+	if(!g) return PT_ERR_ARG;
+	if(!g->active.load()) return group_fail(g, PT_ERR_STATE, "no render was started");
+	group_join(g);
+	g->active.store(1);     // keep the finished render pollable until the next start
+	return g->status.load();
+}
+
+}  // extern "C"
+
+extern "C" {
 
 int pt_debug_primary(pt_ctx* c, int32_t* hit_id, uint64_t* cell_hash) {
 	if(!c) return PT_ERR_ARG;

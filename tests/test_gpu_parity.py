@@ -295,6 +295,45 @@ def test_pipelined_partition_frames(gpu):
     assert (bits(last) == bits(want[-1])).all()
 
 
+@pytest.mark.parametrize("parts", [1, 2, 5])
+def test_group_render_gathers_on_the_device(gpu, parts):
+    """pt_group_*: one frame split over several contexts of one process (here all on the one GPU), partitions copied
+    device to device into the root's gathered buffer, assembled there, downloaded once.  Bit-identical to the
+    unpartitioned image, also for a ragged image size and on repeated use of the group; after an abort only finished
+    pixels are written and the progress record counts them."""
+    world, objs = scenes.mixed_scene(seed=7, n=40)
+    group = api.Group([0] * parts)
+    for w, h, spp in ((200, 117, 16), (333, 77, 8)):
+        st = settings_for("mixed40", w, h, spp, 8)
+        whole = gpu.render(world, objs, st)
+        img = group.render(world, objs, st, out=np.full((h, w, 3), -3.0, np.float32))
+        assert (bits(img) == bits(whole)).all()
+        p = group.progress()
+        assert p.done == 1 and p.aborted == 0 and p.fraction == 1.0 and p.paths_done == gpu.stats().paths
+        assert sum(group.part_stats(k).paths for k in range(parts)) == gpu.stats().paths
+    # abort: a long frame, stopped early
+    world, objs = scenes.glass_scene(seed=3, per_type=16)
+    st = settings_for("glass", 1280, 720, 256, 32)
+    whole = gpu.render(world, objs, st)
+    out = np.full((720, 1280, 3), -3.0, np.float32)
+    group.start(world, objs, st, out=out)
+    t0 = time.time()
+    while time.time() - t0 < 60:
+        p = group.progress()
+        if p.done or p.fraction > 0.2:
+            break
+        time.sleep(0.001)
+    group.abort()
+    group.wait()
+    p = group.progress()
+    assert p.done == 1 and p.aborted == 1
+    written = (out != -3.0).all(axis=2)
+    assert ((out == -3.0).all(axis=2) | written).all() and 0 < written.sum() < 1280 * 720
+    assert (bits(out[written]) == bits(whole[written])).all()
+    assert p.fraction == pytest.approx(written.sum() / (1280 * 720), abs=1e-6)
+    group.close()
+
+
 def test_headless_harness(gpu, tmp_path):
     """The C++ harness drives start / progress / wait through the C ABI and writes the image."""
     import json
@@ -319,6 +358,15 @@ def test_headless_harness(gpu, tmp_path):
     assert (bits(got) == bits(want)).all()
     body = open(ppm, "rb").read()
     assert body.startswith(b"P6") and len(body) >= 160 * 90 * 3
+    # several partitions through the group calls (three contexts on the one GPU): the gathered and assembled image is the same
+    r = subprocess.run([exe, "--scene", scene_file, "--size", "160x90", "--spp", "16", "--bounces", "8", "--seed", "4242",
+                        "--gpus", "0,0,0", "--pfm", pfm, "--quiet"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["paths"] == gpu.stats().paths and info["gpus"] == 3 and info["aborted"] == 0
+    raw = open(pfm, "rb").read()
+    got = np.frombuffer(raw[-160 * 90 * 12:], np.float32).reshape(90, 160, 3)[::-1]
+    assert (bits(got) == bits(want)).all()
     # abort path: a long render stopped from the frame loop still ends cleanly
     r = subprocess.run([exe, "--scene", scene_file, "--size", "1920x1080", "--spp", "256", "--bounces", "32", "--abort-after", "0.02",
                         "--poll-ms", "2", "--quiet"], capture_output=True, text=True, timeout=120)

@@ -153,3 +153,14 @@ def test_bench_workloads_and_cpu_leg():
     assert row["paths"] > 0 and row["seconds_1_threads"] > 0 and row["mpaths_per_s_2_threads"] > 0
     counters = {k: 1 for k in list(bench.FLOP_WEIGHTS) + ["uneven_sphere"]}
     assert bench.flops_from_counters(counters) == sum(v for k, v in bench.FLOP_WEIGHTS.items() if k != "unit_space") + 3 * bench.FLOP_WEIGHTS["unit_space"]
+
+
+@pytest.mark.parametrize("name,tolerance", [("demo-1080p-64spp-d8", 0.01), ("glass-1080p-128spp-d32", 0.01), ("mixed9-1080p-64spp-d16", 0.02)])
+def test_known_flops_per_path(name, tolerance):
+    """The flop-per-path figures bench.py quotes when its CPU leg is skipped: event counters of the oracle times the
+    per-event weights, here on the same scene and samples per pixel at a small image size."""
+    import bench
+    world, objs, kw = bench.workload(name)
+    got, counters = bench.oracle_flops_per_path(world, objs, kw, 4e5)
+    assert counters["paths"] > 1e5
+    assert got == pytest.approx(bench.KNOWN_FLOPS_PER_PATH[name], rel=tolerance)
