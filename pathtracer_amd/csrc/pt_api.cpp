@@ -72,8 +72,7 @@ struct pt_ctx {
 	size_t static_scratch_bytes = 0;
 	uint32_t* abort_flag = nullptr;      // host-pinned, read by the trace kernel
 	uint32_t* abort_flag_dev = nullptr;  // the same word as the device addresses it
-	uint32_t* progress_word = nullptr;   // host-pinned: the trace kernel notes here how many work groups have been handed out
-	uint32_t* progress_word_dev = nullptr;
+	uint32_t* progress_word = nullptr;   // host-pinned, PT_PROGRESS_WORD words behind the abort word: the trace kernel notes here how many work groups have been handed out
 	uint64_t launches_since_readout = 0; // pt_trace calls since the statistics were last folded
 	int counter_set = 0;                 // which of the two sets of group counters the next launch uses
 	ptl::TraceJob job{};
@@ -503,13 +502,11 @@ int trace(pt_ctx* c, float* d_rgb, hipStream_t stream, bool sync, bool write_thr
 	if(d_rgb) job.fb = d_rgb;
 	hipStream_t s = stream ? stream : c->stream;
 	c->last_stream = s;
-	if(++c->serial == 0) c->serial = 1;
-	job.serial = c->serial;
-	job.write_through = write_through ? 1 : 0;
+	if(++c->serial >= 0x80000000u) c->serial = 1;
+	job.serial = c->serial | (write_through ? 0x80000000u : 0u);
 	job.group_counter = c->counter.as<uint32_t>() + (size_t)c->counter_set * 1024;
 	job.group_counter_next = c->counter.as<uint32_t>() + (size_t)(c->counter_set ^ 1) * 1024;
-	job.progress = write_through ? c->progress_word_dev : nullptr;
-	if(write_through) *c->progress_word = 0;
+	*c->progress_word = 0;
 	c->counter_set ^= 1;
 	{ std::lock_guard<std::mutex> l(c->mu); c->live_job = job; c->live_paths = c->stats.paths; c->live_valid = true; }
 	// HIP events around the two kernels give the statistics their durations, and cost a few microseconds of a frame
@@ -772,13 +769,12 @@ pt_ctx* pt_create(int device) {
 	c->device = device;
 	bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
 	          hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess &&
-	          hipHostMalloc((void**)&c->abort_flag, 64, hipHostMallocMapped) == hipSuccess &&
-	          hipHostMalloc((void**)&c->progress_word, 64, hipHostMallocMapped) == hipSuccess;
+	          hipHostMalloc((void**)&c->abort_flag, 256, hipHostMallocMapped) == hipSuccess;
 	if(!ok) { fail(nullptr, PT_ERR_DEVICE, "stream / pinned memory creation failed: %s", hipGetErrorString(hipGetLastError())); pt_destroy(c); return nullptr; }
+	c->progress_word = c->abort_flag + PT_PROGRESS_WORD;
 	*c->abort_flag = 0;
 	*c->progress_word = 0;
 	if(hipHostGetDevicePointer((void**)&c->abort_flag_dev, c->abort_flag, 0) != hipSuccess) c->abort_flag_dev = c->abort_flag;
-	if(hipHostGetDevicePointer((void**)&c->progress_word_dev, c->progress_word, 0) != hipSuccess) c->progress_word_dev = c->progress_word;
 	// with this context's device current: the address of that device's copy of the static staging array
 	if((e = ptl::static_scratch(&c->static_scratch, &c->static_scratch_bytes)) != hipSuccess) { fail(nullptr, PT_ERR_DEVICE, "hipGetSymbolAddress: %s", hipGetErrorString(e)); pt_destroy(c); return nullptr; }
 	if((e = ptl::query_trace_caps(&c->caps)) != hipSuccess) { fail(nullptr, PT_ERR_DEVICE, "occupancy query failed: %s", hipGetErrorString(e)); pt_destroy(c); return nullptr; }
@@ -795,7 +791,6 @@ void pt_destroy(pt_ctx* c) {
 	for(auto& p : c->pending) for(hipEvent_t e : p) (void)hipEventDestroy(e);
 	for(hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
 	if(c->abort_flag) (void)hipHostFree(c->abort_flag);
-	if(c->progress_word) (void)hipHostFree(c->progress_word);
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 	if(c->side) (void)hipStreamDestroy(c->side);
 	for(hipEvent_t e : c->snap_event) if(e) (void)hipEventDestroy(e);

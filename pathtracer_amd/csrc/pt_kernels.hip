@@ -40,9 +40,10 @@ __device__ __forceinline__ int lanes_below(uint64_t mask) {
 // A range sum and the serial number of the launch that wrote it: one 16-byte store.  An asynchronous render's
 // sums go straight through the caches to memory, where the copy engine finds the finished ones when the host asks
 // for a snapshot of the frame in progress.  (A vector store with cache-bypass bits; nothing else changes.)
+template <bool THROUGH>
 __device__ __forceinline__ void store_sum(const ptl::TraceJob& job, float4* at, float x, float y, float z) {
 	const v4f v = { x, y, z, __uint_as_float(job.serial) };
-	if(job.write_through) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(at), "v"(v) : "memory");
+	if(THROUGH) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(at), "v"(v) : "memory");
 	else *at = make_float4(v.x, v.y, v.z, v.w);
 }
 
@@ -70,7 +71,9 @@ enum { CAST_BRUTE = 0, CAST_GRID_LANE = 1, CAST_GRID_COOP = 2 };
 #ifndef PT_BRUTE_WAVES_PER_SIMD
 #define PT_BRUTE_WAVES_PER_SIMD 5     // the all-features brute-force variant: 96 VGPRs with 16 spilled still beats four wavefronts by 7 %
 #endif
-template <int MODE, int FEAT>
+// THROUGH: the range sums go through the caches to memory (asynchronous renders, whose frames can be polled while they are
+// traced).  A compile-time choice: as a run-time one it cost the demo frame 2.4 % through register pressure alone.
+template <int MODE, int FEAT, bool THROUGH>
 __global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIMD : FEAT == 0 ? PT_PLAIN_WAVES_PER_SIMD : PT_BRUTE_WAVES_PER_SIMD) void pt_k_trace(ptl::TraceJob job) {
 #ifdef PT_COOP_TIMING
 	constexpr bool kWaveLds = true;           // the phase timers live in the per-wave LDS block
@@ -158,7 +161,10 @@ __global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIM
 						if(*job.abort_flag != 0u) {
 							for(uint32_t k = 0; k < kShards; k++) atomicOr(job.group_counter + k * kShardStride, 0x80000000u);
 							g = 0x80000000u;
-						} else if(job.progress) *job.progress = g + 1u;       // groups go out in index order, near enough: a posted write, nobody waits for it
+						}
+						// progress for the host: groups go out in index order, near enough.  The word sits beside the abort word in
+						// pinned host memory; a posted write, nobody waits for it
+						else ((volatile uint32_t*)job.abort_flag)[PT_PROGRESS_WORD] = g + 1u;       // groups go out in index order, near enough: a posted write, nobody waits for it
 					}
 				}
 				g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIM
 						}
 						if(s0 == s1) {
 							// nothing to trace (a bucket without samples, code/raycast.cpp:1270, or fewer samples than ranges)
-							store_sum(job, job.partial + tile_item0 + slot, 0.0f, 0.0f, 0.0f);
+							store_sum<THROUGH>(job, job.partial + tile_item0 + slot, 0.0f, 0.0f, 0.0f);
 						} else {
 							const V3 o = pixel_origin_tab(job, fr, x, y);
 							a = make_uint4((uint32_t)first, (uint32_t)s0 | ((uint32_t)s1 << 16), fr->aperture != 0.0f ? (uint32_t)lens_start(fr, x, y) : 0u, round);
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIM
 					} else { si = 0; si_end = 0; }
 					if(si == si_end) {
 						// nothing to trace (a bucket without samples, code/raycast.cpp:1270, or fewer samples than ranges)
-						store_sum(job, job.partial + item, 0.0f, 0.0f, 0.0f);
+						store_sum<THROUGH>(job, job.partial + item, 0.0f, 0.0f, 0.0f);
 					} else {
 						lens = fr->aperture != 0.0f ? lens_start(fr, px, py) : 0;
 						if(MODE != CAST_GRID_COOP) origin = pixel_origin_tab(job, fr, px, py);
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIM
 				si++;
 				state = NEED_PATH;
 				if(si == si_end) {
-					store_sum(job, job.partial + item, sum.x, sum.y, sum.z);
+					store_sum<THROUGH>(job, job.partial + item, sum.x, sum.y, sum.z);
 					state = NEED_PIXEL;
 				}
 			}
@@ -616,8 +622,9 @@ int coop_stats(unsigned long long* out16) {
 
 namespace {
 enum { V_BRUTE_PLAIN = 0, V_BRUTE = 1, V_GRID_LANE = 2, V_GRID_COOP = 3, V_COUNT = 4 };
-void (*const kTraceKernels[V_COUNT])(TraceJob) = { pt_k_trace<CAST_BRUTE, 0>, pt_k_trace<CAST_BRUTE, FEAT_ALL>, pt_k_trace<CAST_GRID_LANE, FEAT_ALL>,
-                                                   pt_k_trace<CAST_GRID_COOP, FEAT_ALL> };
+void (*const kTraceKernels[2][V_COUNT])(TraceJob) = {
+	{ pt_k_trace<CAST_BRUTE, 0, false>, pt_k_trace<CAST_BRUTE, FEAT_ALL, false>, pt_k_trace<CAST_GRID_LANE, FEAT_ALL, false>, pt_k_trace<CAST_GRID_COOP, FEAT_ALL, false> },
+	{ pt_k_trace<CAST_BRUTE, 0, true>, pt_k_trace<CAST_BRUTE, FEAT_ALL, true>, pt_k_trace<CAST_GRID_LANE, FEAT_ALL, true>, pt_k_trace<CAST_GRID_COOP, FEAT_ALL, true> } };
 }
 
 hipError_t query_trace_caps(TraceCaps* caps) {
@@ -630,7 +637,7 @@ hipError_t query_trace_caps(TraceCaps* caps) {
 	caps->cus = prop.multiProcessorCount;
 	for(int v = 0; v < V_COUNT; v++) {
 		int b = 0;
-		e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, kTraceKernels[v], kBlock, 0);
+		e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, kTraceKernels[0][v], kBlock, 0);      // the write-through twins differ in one store
 		if(e != hipSuccess) return e;
 		caps->blocks_per_cu[v] = b > 0 ? b : 1;
 	}
@@ -648,7 +655,7 @@ hipError_t launch_trace(const TraceJob& job, const TraceCaps& caps, hipStream_t 
 	if(blocks > resident) blocks = resident;
 	if(blocks < 1) blocks = 1;
 	if(grid_blocks_out) *grid_blocks_out = (int)blocks;
-	hipLaunchKernelGGL(kTraceKernels[variant], dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
+	hipLaunchKernelGGL(kTraceKernels[(job.serial >> 31) & 1u][variant], dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
 	return hipGetLastError();
 }
 

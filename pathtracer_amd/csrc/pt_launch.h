@@ -5,6 +5,8 @@
 
 namespace ptl {
 
+#define PT_PROGRESS_WORD 16      // words from the abort word to the progress word (a cache line of its own)
+
 // Plain-data mirrors of the device-side Scene / Frame structs (pt_device.h) so that host code
 // does not need to include device code.
 struct Vec { float x, y, z; };
@@ -46,23 +48,22 @@ struct TraceJob {
 	size_t slots;               // pixel slots of the framebuffer (pixels, or 64 per owned tile when compact)
 	const float* col_frac;      // x / width for every column, y / height for every row
 	const float* row_frac;
-	uint32_t serial;            // marks the range sums of this launch
+	uint32_t serial;            // marks the range sums of this launch (31 bits); top bit set: launch the kernel twin whose sums bypass the caches on
+	                            // their way to memory, so that a snapshot copied out while the frame is being traced finds the finished ones
 	int ranges_log2;            // a pixel's samples are summed in 2^ranges_log2 contiguous ranges
 	float* fb;                  // row-major image, or tile-major [local tile][64][3] when compact
 	float* accum;               // progressive accumulation buffer (same layout as fb), may be null
 	const int32_t* tile_order;  // owned tiles in the order they are dealt (dearest first), or null for index order
 	uint32_t* group_counter;    // device words: this launch's group counters, zero when it starts
 	uint32_t* group_counter_next;   // the next launch's counters, which this launch zeroes (the two sets take turns, so no fill runs between frames)
-	const volatile uint32_t* abort_flag;   // host-pinned word, non-zero = stop fetching tiles
-	volatile uint32_t* progress;           // host-pinned word or null: groups handed out so far, noted at every abort poll
+	const volatile uint32_t* abort_flag;   // host-pinned: word 0 non-zero = stop fetching tiles; word PT_PROGRESS_WORD receives the number of
+	                                       // groups handed out so far at every look at word 0
 	uint64_t* stats;            // device: [0] ray casts
 	int tiles_x, tiles_y;
 	int n_groups;               // tiles owned by this partition x ranges
 	int part_index, part_count;
 	int frame_index;            // -1: every sample; >= 0: one sample, progressive
 	int compact;
-	int write_through;          // 1: range sums bypass the caches on their way to memory, so that a snapshot copied out while
-	                            // the frame is being traced finds the finished ones (asynchronous renders)
 };
 
 // What a launch of the persistent trace kernel needs to know of the device: filled once per context, under that
