@@ -274,13 +274,16 @@ int prepare(pt_ctx* c) {
 		float tf_bits;
 		memcpy(&tf_bits, &tf, 4);
 		auto slot = [&](int p) { return geo.data() + ((size_t)i * 8 + (size_t)p) * 4; };
-		float* g0 = slot(0); g0[0] = r[PT_F_POS]; g0[1] = r[PT_F_POS + 1]; g0[2] = r[PT_F_POS + 2]; g0[3] = r[PT_F_BRADIUS];
-		memcpy(slot(1), r + PT_F_ROT, 16);
-		memcpy(slot(2), r + PT_F_ROTINV, 16);
+		float* g0 = slot(ptl::REC_POS); g0[0] = r[PT_F_POS]; g0[1] = r[PT_F_POS + 1]; g0[2] = r[PT_F_POS + 2]; g0[3] = r[PT_F_BRADIUS];
+		memcpy(slot(ptl::REC_ROT), r + PT_F_ROT, 16);
+		memcpy(slot(ptl::REC_ROTINV), r + PT_F_ROTINV, 16);
+		float* g3 = slot(ptl::REC_DIM); g3[0] = r[PT_F_DIM]; g3[1] = r[PT_F_DIM + 1]; g3[2] = r[PT_F_DIM + 2]; g3[3] = tf_bits;
+		float* g4 = slot(ptl::REC_SCALE); g4[0] = r[PT_F_SCALE]; g4[1] = r[PT_F_SCALE + 1]; g4[2] = r[PT_F_SCALE + 2]; g4[3] = r[PT_F_ROUGH];
+		float* g5 = slot(ptl::REC_SCALEINV); g5[0] = r[PT_F_SCALEINV]; g5[1] = r[PT_F_SCALEINV + 1]; g5[2] = r[PT_F_SCALEINV + 2]; g5[3] = 0;
 		if(type == PT_GEOM_BOX && !(flags & 1)) {
-			// an unrotated box never reads its rotation: the slots hold the corners lineBoxIntersection
-			// derives from position and size (code/raycast.cpp:420-426), in the same fp32 operations
-			float* lo = slot(1), *hi = slot(2);
+			// an unrotated box reads neither its inverse rotation nor its inverse scale: the two slots hold the corners
+			// lineBoxIntersection derives from position and size (code/raycast.cpp:420-426), in the same fp32 operations
+			float* lo = slot(ptl::REC_ROTINV), *hi = slot(ptl::REC_SCALEINV);
 			for(int k = 0; k < 3; k++) {
 				const float half = r[PT_F_DIM + k] / 2;
 				lo[k] = r[PT_F_POS + k] - half;
@@ -288,11 +291,8 @@ int prepare(pt_ctx* c) {
 			}
 			lo[3] = 0; hi[3] = 0;
 		}
-		float* g3 = slot(3); g3[0] = r[PT_F_DIM]; g3[1] = r[PT_F_DIM + 1]; g3[2] = r[PT_F_DIM + 2]; g3[3] = tf_bits;
-		float* g4 = slot(4); g4[0] = r[PT_F_SCALE]; g4[1] = r[PT_F_SCALE + 1]; g4[2] = r[PT_F_SCALE + 2]; g4[3] = r[PT_F_ROUGH];
-		float* g5 = slot(5); g5[0] = r[PT_F_SCALEINV]; g5[1] = r[PT_F_SCALEINV + 1]; g5[2] = r[PT_F_SCALEINV + 2]; g5[3] = 0;
-		float* m0 = slot(6); m0[0] = r[PT_F_COLOR]; m0[1] = r[PT_F_COLOR + 1]; m0[2] = r[PT_F_COLOR + 2]; m0[3] = r[PT_F_REFL];
-		float* m1 = slot(7); m1[0] = r[PT_F_EMIT]; m1[1] = r[PT_F_EMIT + 1]; m1[2] = r[PT_F_EMIT + 2]; m1[3] = r[PT_F_IOR];
+		float* m0 = slot(ptl::REC_COLOR); m0[0] = r[PT_F_COLOR]; m0[1] = r[PT_F_COLOR + 1]; m0[2] = r[PT_F_COLOR + 2]; m0[3] = r[PT_F_REFL];
+		float* m1 = slot(ptl::REC_EMIT); m1[0] = r[PT_F_EMIT]; m1[1] = r[PT_F_EMIT + 1]; m1[2] = r[PT_F_EMIT + 2]; m1[3] = r[PT_F_IOR];
 	}
 
 	int rc;

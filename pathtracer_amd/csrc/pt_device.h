@@ -173,14 +173,12 @@ PT_DEV uint32_t rng_bounded(Rng& r) {
 }
 
 // ---- scene as the kernels see it ----------------------------------------------------------------
-// An entity is one 128-byte record of eight v4f (one cache line, so a lane that tests an entity
-// touches one line, and a wave-uniform index turns into wide scalar loads): six geometry slots read
-// while intersecting and two material slots read once per hit.
-//   G0 pos.xyz | bounding-sphere radius     G1 rot (w,x,y,z)          G2 rotInverse (w,x,y,z)
-//      (an unrotated box keeps its corners pos - dim/2, pos + dim/2 in G1, G2 instead)
-//   G3 dim.xyz | type + flags<<8 (int bits) G4 dimScale.xyz | roughness   G5 dimScaleInverse.xyz | -
-//   M0 colorLinear.rgb | reflectionMod      M1 emitColorLinear.rgb | refractiveIndex
-enum { G_POS = 0, G_ROT = 1, G_ROTINV = 2, G_DIM = 3, G_SCALE = 4, G_SCALEINV = 5, M_COLOR = 6, M_EMIT = 7, G_SLOTS = 8 };
+// An entity is one 128-byte record of eight v4f (one cache line, so a lane that tests an entity touches one line, and a
+// wave-uniform index turns into wide scalar loads); the slots and their order are ptl::REC_* (pt_launch.h).
+enum { G_POS = ptl::REC_POS, G_ROT = ptl::REC_ROT, G_ROTINV = ptl::REC_ROTINV, G_DIM = ptl::REC_DIM, G_SCALE = ptl::REC_SCALE,
+       G_SCALEINV = ptl::REC_SCALEINV, M_COLOR = ptl::REC_COLOR, M_EMIT = ptl::REC_EMIT, G_SLOTS = ptl::REC_SLOTS };
+// the corners of an unrotated box take the place of the two slots it never reads
+enum { G_BOX_LO = ptl::REC_ROTINV, G_BOX_HI = ptl::REC_SCALEINV };
 enum { FLAG_ROTATED = 1, FLAG_EVEN = 2 };
 
 // Material of the entity a ray hit: colorLinear|reflectionMod, emitColorLinear|refractiveIndex, roughness.
@@ -385,8 +383,8 @@ PT_DEV float intersect_kind(const GeoRef& g, v4f p0, v4f p3, V3 rp, V3 rd, V3& p
 		// the bounding radius of a sphere with three equal dims is dim.x * 0.5f, the radius the reference passes
 		distance = hit_sphere(rp, rd, opos, p0.w, pos, nrm);
 	} else if(KIND == KIND_BOX) {
-		// corners of an unrotated box (pos -/+ dim / 2), kept by the host in the record's unused rotation slots
-		v4f lo = g.plane(G_ROT), hi = g.plane(G_ROTINV);
+		// corners of an unrotated box (pos -/+ dim / 2), kept by the host in two slots such a box never reads
+		v4f lo = g.plane(G_BOX_LO), hi = g.plane(G_BOX_HI);
 		distance = hit_slabs(rp, rd, v3(lo.x, lo.y, lo.z), v3(hi.x, hi.y, hi.z), pos, nrm);
 	} else if(KIND == KIND_BOX_ROTATED) {
 		v4f ri = g.plane(G_ROTINV);
@@ -428,7 +426,7 @@ PT_DEV float intersect_mixed(int kind, const GeoRef& g, v4f p0, v4f p3, V3 rp, V
 	V3 dim = v3(p3.x, p3.y, p3.z);
 	if(kind == KIND_SPHERE) return hit_sphere(rp, rd, opos, p0.w, pos, nrm);
 	if(kind == KIND_BOX) {
-		v4f lo = g.plane(G_ROT), hi = g.plane(G_ROTINV);
+		v4f lo = g.plane(G_BOX_LO), hi = g.plane(G_BOX_HI);
 		return hit_slabs(rp, rd, v3(lo.x, lo.y, lo.z), v3(hi.x, hi.y, hi.z), pos, nrm);
 	}
 	const bool isbox = kind == KIND_BOX_ROTATED;
@@ -754,9 +752,21 @@ __device__ unsigned long long g_coop_stats[16];
 #ifdef PT_COOP_TIMING
 #define PT_TICK(var) long long var = clock64()
 #define PT_TOCK(sh_, i, var) { long long now_ = clock64(); if(lane == 0) (sh_).tacc[i] += (unsigned long long)(now_ - var); var = now_; }
+// -DPT_COOP_TIMING_WAITS: slots 6 .. 9 hold, instead of the chunk counts, the cycles up to the issue of the walk's list-bound
+// loads (6), the wait for them (7), the wait for the expand step's list entries (8) and for a chunk's first record loads (9);
+// the waits are forced by s_waitcnt, so the phases' own totals shift a little
+#ifdef PT_COOP_TIMING_WAITS
+#define PT_TOCK_ISSUED(sh_, i, var) PT_TOCK(sh_, i, var)
+#define PT_TOCK_LANDED(sh_, i, var) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PT_TOCK(sh_, i, var) }
+#else
+#define PT_TOCK_ISSUED(sh_, i, var)
+#define PT_TOCK_LANDED(sh_, i, var)
+#endif
 #else
 #define PT_TICK(var)
 #define PT_TOCK(sh_, i, var)
+#define PT_TOCK_ISSUED(sh_, i, var)
+#define PT_TOCK_LANDED(sh_, i, var)
 #endif
 PT_DEV void wave_sync() {
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -819,6 +829,7 @@ PT_DEV void coop_chunk(const Scene& sc, CoopShared& sh, uint32_t base, uint32_t 
 		GeoRef g = { sc.geo, sc.n, id };
 		v4f p0 = g.plane(G_POS), p3 = g.plane(G_DIM);
 		lo = sc.obj_range[2 * id]; hi = sc.obj_range[2 * id + 1];     // wanted after a hit only; asked for now, with the record
+		PT_TOCK_LANDED(sh, 9, tc);
 		distance = KIND == KIND_MIXED ? intersect_mixed(mixed_kind, g, p0, p3, rp, rd, pos, nrm) : intersect_kind<KIND>(g, p0, p3, rp, rd, pos, nrm);
 	}
 	PT_TOCK(sh, 3, tc);
@@ -858,7 +869,7 @@ PT_DEV void coop_chunk(const Scene& sc, CoopShared& sh, uint32_t base, uint32_t 
 	wave_sync();
 	if(key != COOP_NONE && sh.best[owner] == key) put6(sh.res[owner], pos, nrm);
 	PT_TOCK(sh, 5, tc);
-#ifdef PT_COOP_TIMING
+#if defined(PT_COOP_TIMING) && !defined(PT_COOP_TIMING_WAITS)
 	if(lane == 0) sh.tacc[KIND == KIND_MIXED ? 9 : 6 + (KIND >= 3 ? 1 : 0) + (KIND >= 4 ? 1 : 0)] += 1;     // chunks: direct kinds, ellipsoid, cylinder/cone, mixed
 #endif
 }
@@ -971,42 +982,41 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 			#pragma unroll
 			for(int j = 0; j < COOP_CELLS; j++) { ka[j] = sc.cell_start[pc[j]]; kb[j] = sc.cell_start[pc[j] + 1]; }
 		}
-		// Descriptors and sequence positions are dealt cell by cell, all lanes in step (a wave prefix sum per
-		// step, in registers), so that when they run out it is the far cells of every ray that wait for the
-		// next segment, not all cells of some rays.  Within a step the lanes are served in an order that starts
-		// one lane later every segment, so no lane is last for ever.  A list is taken while a descriptor is
-		// free and its first entry lies inside the bitmap; slots and positions grow together, so everything
-		// after the first refusal is refused too (a list may run past the bitmap's end: it is then the last).
+		PT_TOCK_ISSUED(sh, 6, t0);
+		PT_TOCK_LANDED(sh, 7, t0);
+		// Descriptors and sequence positions are dealt ray by ray: two wave prefix sums (lists and entries per lane, in
+		// registers) give every lane the slot and the position its first list starts at, its other lists follow.  The
+		// lanes are served in an order that starts one lane later every segment, so no lane is last for ever.  A list is
+		// taken while a descriptor is free and its first entry lies inside the bitmap; slots and positions grow together,
+		// so everything after the first refusal is refused too (a list may run past the bitmap's end: it is then the last).
 		const uint32_t rot = uniform(sh.turn) & 63u;
-		const uint64_t before_rot = rot ? (1ull << rot) - 1ull : 0ull;
-		uint32_t next_slot = 0, next_pos = 0;          // wave-uniform
-		bool cut = false;
-		uint32_t cut_slot = 0, cut_pos = 0;
-		bool open = walking;
+		uint32_t my_lists = 0, my_entries = 0;
+		#pragma unroll
+		for(int j = 0; j < COOP_CELLS; j++) {
+			const uint32_t c = (walking && j < m) ? kb[j] - ka[j] : 0u;
+			my_lists += c > 0 ? 1u : 0u;
+			my_entries += c;
+		}
+		uint32_t slot, start, all_lists, all_entries;
+		{
+			const uint32_t upto_l = wave_inclusive_sum(my_lists), upto_e = wave_inclusive_sum(my_entries);
+			all_lists = (uint32_t)__builtin_amdgcn_readlane((int)upto_l, 63);
+			all_entries = (uint32_t)__builtin_amdgcn_readlane((int)upto_e, 63);
+			const uint32_t skipped_l = rot ? (uint32_t)__builtin_amdgcn_readlane((int)upto_l, (int)rot - 1) : 0u;   // of the lanes served last
+			const uint32_t skipped_e = rot ? (uint32_t)__builtin_amdgcn_readlane((int)upto_e, (int)rot - 1) : 0u;
+			const bool early = (uint32_t)lane >= rot;
+			slot = (upto_l - my_lists) + (early ? 0u - skipped_l : all_lists - skipped_l);
+			start = (upto_e - my_entries) + (early ? 0u - skipped_e : all_entries - skipped_e);
+		}
+		bool open = walking, turned_away = false;
 		#pragma unroll
 		for(int j = 0; j < COOP_CELLS; j++) {
 			const bool here = open && j < m;
 			const uint32_t c = here ? kb[j] - ka[j] : 0u;
-			const uint32_t upto = wave_inclusive_sum(c);
-			const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)upto, 63);
-			const uint32_t skipped = rot ? (uint32_t)__builtin_amdgcn_readlane((int)upto, (int)rot - 1) : 0u;   // entries of the lanes served last
-			const uint64_t listed = __ballot(c > 0);
-			const uint32_t lists = (uint32_t)__popcll(listed), lists_skipped = (uint32_t)__popcll(listed & before_rot);
-			const bool early = (uint32_t)lane >= rot;
-			const uint32_t slot = next_slot + (uint32_t)lanes_under(listed) + (early ? 0u - lists_skipped : lists - lists_skipped);
-			const uint32_t start = next_pos + (upto - c) + (early ? 0u - skipped : all - skipped);
-			const bool refused = c > 0 && (cut || slot >= (uint32_t)COOP_DESCS || start >= COOP_SEQ_MAX);
-			const uint64_t turned_away = __ballot(refused);
-			if(turned_away != 0 && !cut) {
-				const uint64_t in_order = rot ? (turned_away >> rot) | (turned_away << (64u - rot)) : turned_away;
-				const int first = (int)(((uint32_t)__ffsll((unsigned long long)in_order) - 1u + rot) & 63u);
-				cut = true;
-				cut_slot = (uint32_t)__builtin_amdgcn_readlane((int)slot, first);
-				cut_pos = (uint32_t)__builtin_amdgcn_readlane((int)start, first);
-			}
 			if(c > 0) {
-				if(refused) {
-					open = false;          // this cell and the ones after it wait for the next segment
+				if(slot >= (uint32_t)COOP_DESCS || start >= COOP_SEQ_MAX) {
+					open = false;          // this cell and the ones after it wait for the next segment; slot and start stay at the refusal
+					turned_away = true;
 				} else {
 					sh.desc_k0[slot] = ka[j];
 					// the face the ray came in through, from the coordinate that changed: -x +x -y +y -z +z
@@ -1017,11 +1027,22 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 					}
 					sh.desc_at[slot] = (start << 12) | (uint32_t)lane | ((uint32_t)j << 6) | (face << 9);
 					atomicOr(&sh.head[start >> 5], 1u << (start & 31u));       // start < COOP_SEQ_MAX for every list taken
+					slot += 1u;
+					start += c;
 				}
 			}
 			if(here && open) { sh.cells[j][lane] = cc[j]; recorded = j + 1; }
-			next_slot += lists;
-			next_pos += all;
+		}
+		// the first refusal in serving order ends the sequence: what was placed before it is contiguous from zero
+		uint32_t ndesc = all_lists, total = all_entries;
+		{
+			const uint64_t refusals = __ballot(turned_away);
+			if(refusals != 0) {
+				const uint64_t in_order = rot ? (refusals >> rot) | (refusals << (64u - rot)) : refusals;
+				const int first = (int)(((uint32_t)__ffsll((unsigned long long)in_order) - 1u + rot) & 63u);
+				ndesc = (uint32_t)__builtin_amdgcn_readlane((int)slot, first);
+				total = (uint32_t)__builtin_amdgcn_readlane((int)start, first);
+			}
 		}
 		if(walking) {
 			sh.ncell[lane] = (uint8_t)recorded;
@@ -1031,8 +1052,6 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 		PT_TOCK(sh, 10, t0);
 
 		// ---- expand: the lists of all lanes as one sequence, 64 entries per round ------------------
-		const uint32_t ndesc = cut ? cut_slot : next_slot;
-		const uint32_t total = cut ? cut_pos : next_pos;
 		// Which list an entry position belongs to: descriptors are in position order, so it is the number of
 		// list heads at or before the position, less one - a prefix count per bitmap word plus a popcount.
 		{
@@ -1068,6 +1087,8 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 				e[u] = sc.entries[k];
 				id[u] = sc.cell_items[k];
 			}
+			PT_TOCK_ISSUED(sh, 11, t0);
+			PT_TOCK_LANDED(sh, 8, t0);
 			#pragma unroll
 			for(int u = 0; u < COOP_ITEMS; u++) {
 				if(live[u]) {

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kBlock) void pt_k_grid_count(ptl::GridBuildJob job)
 	const int i = blockIdx.x * kBlock + threadIdx.x;
 	if(i >= job.n) return;
 	const CellRange r = range_of(job, i);
-	const int tf = __float_as_int(job.geo[(size_t)i * 8 + 3].w);
+	const int tf = __float_as_int(job.geo[(size_t)i * 8 + ptl::REC_DIM].w);
 	const int type = tf & 0xff, flags = tf >> 8;
 	const uint32_t kind = type == PT_GEOM_SPHERE ? ((flags & 2) ? 0u : 3u) : type == PT_GEOM_BOX ? ((flags & 1) ? 2u : 1u) : type == PT_GEOM_CYLINDER ? 4u : 5u;
 	job.obj_range[2 * (size_t)i] = (uint32_t)r.a[0] | ((uint32_t)r.a[1] << 10) | ((uint32_t)r.a[2] << 20) | ((kind & 3u) << 30);

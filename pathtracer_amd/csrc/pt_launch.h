@@ -11,6 +11,15 @@ namespace ptl {
 // does not need to include device code.
 struct Vec { float x, y, z; };
 
+// Slots of an entity's 128-byte device record (eight float4).  What every intersection test reads sits in the first
+// 64 bytes, what only a hit needs (rotation and scale back to world space, the material) in the second.  (Measured on the
+// 100 000-entity scene: the bytes fetched per frame are the same as with the two halves interleaved - a miss in L2 brings
+// the whole line in either way.)
+//   REC_POS pos.xyz | bounding-sphere radius     REC_ROTINV rotInverse (w,x,y,z)     REC_DIM dim.xyz | type + flags<<8 (int bits)
+//   REC_SCALEINV dimScaleInverse.xyz | -         (an unrotated box keeps its corners pos - dim/2, pos + dim/2 in REC_ROTINV, REC_SCALEINV)
+//   REC_ROT rot (w,x,y,z)     REC_SCALE dimScale.xyz | roughness     REC_COLOR colorLinear.rgb | reflectionMod     REC_EMIT emitColorLinear.rgb | refractiveIndex
+enum { REC_POS = 0, REC_ROTINV = 1, REC_DIM = 2, REC_SCALEINV = 3, REC_ROT = 4, REC_SCALE = 5, REC_COLOR = 6, REC_EMIT = 7, REC_SLOTS = 8 };
+
 struct GridDev { int cmin[3], cnt[3], cs[3]; float inv_cs[3]; };
 
 struct SceneDev {
