@@ -164,3 +164,17 @@ def test_known_flops_per_path(name, tolerance):
     got, counters = bench.oracle_flops_per_path(world, objs, kw, 4e5)
     assert counters["paths"] > 1e5
     assert got == pytest.approx(bench.KNOWN_FLOPS_PER_PATH[name], rel=tolerance)
+
+
+def test_host_stages_under_sanitizers(tmp_path):
+    """The library's host stages and scene-file reader compiled for the host alone with -fsanitize=address,undefined and
+    driven by tests/native/host_san_driver.cpp (300 entities, every sample count and tile width, four grid hints)."""
+    import subprocess
+    exe = str(tmp_path / "host_san")
+    src = [os.path.join(ROOT, "tests", "native", "host_san_driver.cpp"), os.path.join(ROOT, "pathtracer_amd", "csrc", "pt_host.cpp")]
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "pathtracer_amd", "csrc")] + src + ["-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
+    assert r.stdout.startswith("checksum")

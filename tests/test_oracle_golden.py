@@ -201,3 +201,20 @@ def test_range_sums_only_move_rounding(oracle_lib):
     assert np.abs(imgs[2].astype(np.float64) - imgs[1]).max() <= 4e-6
     assert np.abs(imgs[8].astype(np.float64) - imgs[1]).max() <= 4e-6
     assert (imgs[2] != imgs[1]).any() or (imgs[8] != imgs[1]).any()
+
+
+def test_oracle_under_sanitizers():
+    """The CPU restatement, driven through its whole surface by oracle/san_driver.c (two scenes, both seed policies, the
+    threaded renderer, casts, progressive frames), built with -fsanitize=address,undefined and with -fsanitize=thread:
+    no report from either, and the same checksum from both."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "san"])
+    sums = []
+    for name in ("san_asan", "san_tsan"):
+        r = subprocess.run([os.path.join(root, "oracle", "_san", name)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert not re.search(r"Sanitizer|runtime error", r.stderr), r.stderr[-2000:]
+        sums.append(r.stdout.strip())
+    assert sums[0] == sums[1] and sums[0].startswith("checksum")
