@@ -303,6 +303,7 @@ const char* pt_group_last_error(const pt_group* group);
 int pt_group_render_start(pt_group* group, const pt_world* world, const pt_object* objects, int n_objects,
                           const pt_settings* settings, float* rgb);
 int pt_group_render_progress(pt_group* group, pt_progress* info);
+int pt_group_render_snapshot(pt_group* group, float* rgb, uint64_t* pixels_done);
 int pt_group_render_abort(pt_group* group);
 int pt_group_render_wait(pt_group* group);
 

@@ -169,6 +169,7 @@ def load_core():
     lib.pt_group_render_start.argtypes = [C.c_void_p, C.POINTER(pt_world), C.POINTER(pt_object), C.c_int,
                                           C.POINTER(pt_settings), C.POINTER(C.c_float)]
     lib.pt_group_render_progress.argtypes = [C.c_void_p, C.POINTER(pt_progress)]
+    lib.pt_group_render_snapshot.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
     lib.pt_group_render_abort.argtypes = [C.c_void_p]
     lib.pt_group_render_wait.argtypes = [C.c_void_p]
     lib.pt_image_alloc.restype = C.POINTER(C.c_float)
@@ -409,6 +410,11 @@ class Group:
         p = pt_progress()
         self._check(self.lib.pt_group_render_progress(self.g, C.byref(p)), "pt_group_render_progress")
         return p
+
+    def snapshot(self, out=None):
+        n = C.c_uint64(0)
+        self._check(self.lib.pt_group_render_snapshot(self.g, fptr(self._out if out is None else out), C.byref(n)), "pt_group_render_snapshot")
+        return n.value
 
     def abort(self):
         self._check(self.lib.pt_group_render_abort(self.g), "pt_group_render_abort")

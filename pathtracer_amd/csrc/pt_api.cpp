@@ -975,15 +975,8 @@ int pt_render_progress(pt_ctx* c, pt_progress* info) {
 	return PT_OK;
 }
 
-int pt_render_snapshot(pt_ctx* c, float* rgb, uint64_t* pixels_done) {
-	if(!c) return PT_ERR_ARG;
-	if(!rgb) return fail(c, PT_ERR_ARG, "null output");
-	if(pixels_done) *pixels_done = 0;
-	if(!c->active.load()) return fail(c, PT_ERR_STATE, "no render was started");
-	if(c->done.load()) {                       // the caller's image already holds every pixel that counts
-		if(pixels_done) *pixels_done = c->done_pixels.load();
-		return c->status.load();
-	}
+// The pixels of one context's frame in flight that are finished, copied into the caller's image.
+static int snapshot_live(pt_ctx* c, float* rgb, uint64_t* pixels_done) {
 	ptl::TraceJob job;
 	bool valid;
 	{ std::lock_guard<std::mutex> l(c->mu); job = c->live_job; valid = c->live_valid; }
@@ -1050,6 +1043,18 @@ int pt_render_snapshot(pt_ctx* c, float* rgb, uint64_t* pixels_done) {
 	}
 	if(pixels_done) *pixels_done = pixels;
 	return PT_OK;
+}
+
+int pt_render_snapshot(pt_ctx* c, float* rgb, uint64_t* pixels_done) {
+	if(!c) return PT_ERR_ARG;
+	if(!rgb) return fail(c, PT_ERR_ARG, "null output");
+	if(pixels_done) *pixels_done = 0;
+	if(!c->active.load()) return fail(c, PT_ERR_STATE, "no render was started");
+	if(c->done.load()) {                       // the caller's image already holds every pixel that counts
+		if(pixels_done) *pixels_done = c->done_pixels.load();
+		return c->status.load();
+	}
+	return snapshot_live(c, rgb, pixels_done);
 }
 
 int pt_render_abort(pt_ctx* c) {
@@ -1273,6 +1278,26 @@ int pt_group_render_progress(pt_group* g, pt_progress* info) {
 	}
 	info->fraction = (float)(share / (double)g->part.size());
 	info->paths_done = paths;
+	return PT_OK;
+}
+
+int pt_group_render_snapshot(pt_group* g, float* rgb, uint64_t* pixels_done) {
+	if(!g) return PT_ERR_ARG;
+	if(!rgb) return group_fail(g, PT_ERR_ARG, "null output");
+	if(pixels_done) *pixels_done = 0;
+	if(!g->active.load()) return group_fail(g, PT_ERR_STATE, "no render was started");
+	if(g->done.load()) {
+		if(pixels_done) *pixels_done = g->aborted.load() ? g->done_pixels.load() : g->total_pixels;
+		return g->status.load();
+	}
+	uint64_t total = 0;
+	for(pt_ctx* c : g->part) {                 // every partition writes its own pixels of the one image
+		uint64_t pixels = 0;
+		int rc = snapshot_live(c, rgb, &pixels);
+		if(rc != PT_OK) return group_fail(g, rc, pt_last_error(c));
+		total += pixels;
+	}
+	if(pixels_done) *pixels_done = total;
 	return PT_OK;
 }
 

@@ -317,12 +317,17 @@ def test_group_render_gathers_on_the_device(gpu, parts):
     whole = gpu.render(world, objs, st)
     out = np.full((720, 1280, 3), -3.0, np.float32)
     group.start(world, objs, st, out=out)
+    snap = np.full_like(out, -3.0)
+    seen = 0
     t0 = time.time()
     while time.time() - t0 < 60:
         p = group.progress()
         if p.done or p.fraction > 0.2:
             break
-        time.sleep(0.001)
+        seen = group.snapshot(snap)              # every partition's finished pixels, scattered into the one image
+    shown = (snap != -3.0).all(axis=2)
+    assert int(shown.sum()) == seen and ((snap == -3.0).all(axis=2) | shown).all()
+    assert (bits(snap[shown]) == bits(whole[shown])).all()
     group.abort()
     group.wait()
     p = group.progress()
