@@ -29,7 +29,9 @@ if buf[5]:
 tn = {2: "chunk_fetch", 3: "chunk_intersect", 4: "chunk_cellsearch", 5: "chunk_writeback"}
 for i in range(2, 6):
     print(f"  {tn[i]:20s} {buf[i]:14d}  {100.0 * buf[i] / max(1, buf[0]):5.1f} % of wave time   per segment {buf[i] / max(1, buf[1]):8.0f}")
-print("  chunks direct/ellipsoid/cyl+cone", buf[6], buf[7], buf[8])
+print("  chunks direct/ellipsoid/cyl+cone/mixed", buf[6], buf[7], buf[8], buf[9])
+print("  (a -DPT_COOP_TIMING_WAITS build keeps cycles in those four instead: walk until its loads are issued %.1f %%, wait for them %.1f %%,"
+      " wait for list entries %.1f %%, wait for a chunk's first records %.1f %% of wave time)" % tuple(100.0 * buf[i] / max(1, buf[0]) for i in (6, 7, 8, 9)))
 for i in range(10, 16):
     print(f"  {names[i]:20s} {buf[i]:14d}  {100.0 * buf[i] / max(1, buf[0]):5.1f} % of wave time   per segment {buf[i] / max(1, buf[1]):8.0f}")
 for i in range(1, 10):
