@@ -679,7 +679,7 @@ PT_DEV int cast(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface& surf
 // code/raycast.cpp:957-983) is restored exactly by a 64-bit key (cell ordinal | distance bits | id)
 // reduced with an LDS atomic min per ray.
 #ifndef PT_COOP_CELLS
-#define PT_COOP_CELLS 6
+#define PT_COOP_CELLS 7
 #endif
 #ifndef PT_COOP_MIN_WALKING
 #define PT_COOP_MIN_WALKING 48
@@ -689,7 +689,7 @@ constexpr int COOP_CELLS = PT_COOP_CELLS;               // cells a lane records 
 #define PT_COOP_POOL 256
 #endif
 #ifndef PT_COOP_DESCS
-#define PT_COOP_DESCS 338
+#define PT_COOP_DESCS 306
 #endif
 constexpr int COOP_POOL = PT_COOP_POOL;                 // candidates awaiting their intersection test
 constexpr int COOP_DESCS = PT_COOP_DESCS;               // non-empty cells the wavefront can note per segment
