@@ -575,6 +575,22 @@ def test_start_progress_abort(gpu):
     sc.close()
 
 
+def test_page_locked_image(gpu):
+    """pt_image_alloc: the finished image is copied straight into a page-locked buffer; same floats as into a pageable
+    one (which goes through the staging image and the mover threads from 4 MB up: 1280x720 is 11 MB)."""
+    world, objs = scenes.mixed_scene(seed=7, n=40)
+    st = settings_for("mixed40", 1280, 720, 4, 4)
+    pageable = gpu.render(world, objs, st).copy()
+    image = gpu.image_alloc(1280, 720)
+    image[:] = -1
+    gpu.start(world, objs, st, out=image)
+    gpu.wait()
+    assert (bits(image) == bits(pageable)).all()
+    gpu.image_free(image)
+    with pytest.raises(api.PtError):
+        gpu.image_alloc(0, 10)
+
+
 def test_srgb8_present(gpu):
     """Screenshot bytes are the CPU path's, bit for bit: over a rendered image, over a sample of every
     magnitude including the neighbourhood of each step of the encoder, and - through the histogram of a
