@@ -768,6 +768,12 @@ __device__ unsigned long long g_coop_stats[16];
 #define PT_TOCK_ISSUED(sh_, i, var)
 #define PT_TOCK_LANDED(sh_, i, var)
 #endif
+// -DPT_ASM_MARKS: named comments in the assembly output, so that a script can count the instructions between them
+#ifdef PT_ASM_MARKS
+#define PT_MARK(name) asm volatile("; PTMARK " name ::: "memory")
+#else
+#define PT_MARK(name)
+#endif
 PT_DEV void wave_sync() {
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
@@ -802,10 +808,11 @@ PT_DEV bool sphere_rejects(V3 rp, V3 rd, v4f p0) {
 	return !may_hit;
 }
 
-// One chunk of up to 64 same-kind candidates, one per lane.  Called by the whole wavefront: the
-// rendezvous between the atomic min and the winner's write-back must be reached by all 64 lanes.
+// One chunk of up to 64 candidates of one kind (or of any, KIND_MIXED), one per lane, taken from list[base .. end).  Called by
+// the whole wavefront: the rendezvous between the atomic min and the winner's write-back must be reached by all 64 lanes.
 template <int KIND>
-PT_DEV void coop_chunk(const Scene& sc, CoopShared& sh, uint32_t base, uint32_t end, int lane) {
+PT_DEV void coop_chunk(const Scene& sc, CoopShared& sh, const uint32_t* list, uint32_t base, uint32_t end, int lane) {
+PT_MARK("chunk_begin");
 	uint32_t i = base + (uint32_t)lane;
 	unsigned long long key = COOP_NONE;
 	int owner = 0;
@@ -817,13 +824,14 @@ PT_DEV void coop_chunk(const Scene& sc, CoopShared& sh, uint32_t base, uint32_t 
 	int id = 0, mixed_kind = 0;
 	V3 rp = v3(0, 0, 0), rd = v3(0, 0, 1);
 	if(i < end) {
-		uint32_t entry = sh.sorted[i];
+		uint32_t entry = list[i];
 		owner = (int)(entry >> 26);
 		id = (int)(entry & 0x7fffffu);
 		mixed_kind = (int)((entry >> 23) & 7u);
 		get6(sh.ray[owner], rp, rd);
 	}
 	PT_TOCK(sh, 2, tc);
+PT_MARK("chunk_fetched");
 	uint32_t lo = 0, hi = 0;
 	if(i < end) {
 		GeoRef g = { sc.geo, sc.n, id };
@@ -833,42 +841,71 @@ PT_DEV void coop_chunk(const Scene& sc, CoopShared& sh, uint32_t base, uint32_t 
 		distance = KIND == KIND_MIXED ? intersect_mixed(mixed_kind, g, p0, p3, rp, rd, pos, nrm) : intersect_kind<KIND>(g, p0, p3, rp, rd, pos, nrm);
 	}
 	PT_TOCK(sh, 3, tc);
-	if(i < end) {
-		if(distance > 0) {
-			// The hit counts for the first recorded cell that lists the entity and whose box holds the
-			// hit point, bounds included (code/raycast.cpp:957-983, pointInBox).  Per axis at most three
-			// cells around the point's quotient can hold it; the exact comparison against their bounds
-			// gives the interval of admissible cell coordinates, which is then cut to the entity's range.
+PT_MARK("chunk_intersected");
+	// The hit counts for the first recorded cell that lists the entity and whose box holds the hit point, bounds
+	// included (code/raycast.cpp:957-983, pointInBox).  Cell bounds are integers (coordinate * cell size), exact as
+	// floats, so per axis the cells whose closed box holds the point are floor(p / size) and, when p sits on its lower
+	// bound, the one before.  Nearly every point sits on no bound: then one cell can hold it, and the search through
+	// the recorded cells is a comparison of packed coordinates.
+	const bool hit = i < end && distance > 0;
+	int ordinal = -1;
+	int q[3] = { 0, 0, 0 };
+	uint32_t on_bound = 0;
+	if(hit) {
+		const float pc[3] = { pos.x, pos.y, pos.z };
+		bool listed = true;
+		int rel[3];
+		#pragma unroll
+		for(int a = 0; a < 3; a++) {
+			const int cs = sc.grid.cs[a];
+			int k = (int)floorf(pc[a] * sc.grid.inv_cs[a]);                // within one of the true quotient's floor
+			if((float)(k * cs) > pc[a]) k--;
+			else if((float)((k + 1) * cs) <= pc[a]) k++;
+			if((float)(k * cs) == pc[a]) on_bound |= 1u << a;
+			q[a] = k;
+			rel[a] = k - sc.grid.cmin[a];
+			const int lo_a = (int)((lo >> (10 * a)) & 1023u), hi_a = (int)((hi >> (10 * a)) & 1023u);
+			listed = listed && (uint32_t)(rel[a] - lo_a) <= (uint32_t)(hi_a - lo_a);
+		}
+		const uint32_t target = (on_bound == 0 && listed) ? pack_cell(rel[0], rel[1], rel[2]) : 0xffffffffu;    // no recorded cell looks like the latter
+		#pragma unroll
+		for(int o = COOP_CELLS - 1; o >= 0; o--) {
+			if(sh.cells[o][owner] == target) ordinal = o;
+		}
+		if(ordinal >= (int)sh.ncell[owner]) ordinal = -1;           // a leftover of an earlier segment; any true match lies before it
+	}
+	if(__ballot(hit && on_bound != 0) != 0) {
+		// a point on a cell's lower bound: the interval of admissible coordinates per axis, cut to the entity's range
+		if(hit && on_bound != 0) {
 			int amin[3], amax[3];
-			const float pc[3] = { pos.x, pos.y, pos.z };
 			#pragma unroll
 			for(int a = 0; a < 3; a++) {
-				// cell bounds are integers (coordinate * cell size), exact as floats, so the cells whose
-				// closed box holds the point are floor(p / size) and, when p sits on its lower bound, the one before
-				const int cs = sc.grid.cs[a], cmin = sc.grid.cmin[a];
-				int q = (int)floorf(pc[a] * sc.grid.inv_cs[a]);                // within one of the true quotient's floor
-				if((float)(q * cs) > pc[a]) q--;
-				else if((float)((q + 1) * cs) <= pc[a]) q++;
-				const int first = (float)(q * cs) == pc[a] ? q - 1 : q;
+				const int cmin = sc.grid.cmin[a];
+				const int first = ((on_bound >> a) & 1u) ? q[a] - 1 : q[a];
 				amin[a] = imax(first - cmin, (int)((lo >> (10 * a)) & 1023u));
-				amax[a] = imin(q - cmin, (int)((hi >> (10 * a)) & 1023u));
+				amax[a] = imin(q[a] - cmin, (int)((hi >> (10 * a)) & 1023u));
 			}
 			const int n = (int)sh.ncell[owner];
-			int ordinal = -1;
 			#pragma unroll
 			for(int o = COOP_CELLS - 1; o >= 0; o--) {
 				const uint32_t c = sh.cells[o][owner];
 				const int cx = (int)(c & 1023u), cy = (int)((c >> 10) & 1023u), cz = (int)((c >> 20) & 1023u);
 				if(o < n && cx >= amin[0] && cx <= amax[0] && cy >= amin[1] && cy <= amax[1] && cz >= amin[2] && cz <= amax[2]) ordinal = o;
 			}
-			if(ordinal >= 0) key = ((unsigned long long)ordinal << 55) | ((unsigned long long)__float_as_uint(distance) << 23) | (unsigned long long)id;
 		}
-		if(key != COOP_NONE) { atomicMin(&sh.best[owner], key); PT_STAT(8, 1); }
+	}
+PT_MARK("chunk_searched");
+	if(ordinal >= 0) {
+		key = ((unsigned long long)ordinal << 55) | ((unsigned long long)__float_as_uint(distance) << 23) | (unsigned long long)id;
+		atomicMin(&sh.best[owner], key);
+		PT_STAT(8, 1);
 	}
 	PT_TOCK(sh, 4, tc);
 	wave_sync();
+PT_MARK("chunk_synced");
 	if(key != COOP_NONE && sh.best[owner] == key) put6(sh.res[owner], pos, nrm);
 	PT_TOCK(sh, 5, tc);
+PT_MARK("chunk_end");
 #if defined(PT_COOP_TIMING) && !defined(PT_COOP_TIMING_WAITS)
 	if(lane == 0) sh.tacc[KIND == KIND_MIXED ? 9 : 6 + (KIND >= 3 ? 1 : 0) + (KIND >= 4 ? 1 : 0)] += 1;     // chunks: direct kinds, ellipsoid, cylinder/cone, mixed
 #endif
@@ -876,34 +913,41 @@ PT_DEV void coop_chunk(const Scene& sc, CoopShared& sh, uint32_t base, uint32_t 
 
 // Tests everything in the pool and empties it.  Whole wavefront.
 PT_DEV void coop_drain(const Scene& sc, CoopShared& sh, int lane) {
-	uint32_t off[KIND_COUNT + 1];
-	off[0] = 0;
-	#pragma unroll
-	for(int k = 0; k < KIND_COUNT; k++) off[k + 1] = off[k] + uniform(sh.count[k]);
-	const uint32_t total = off[KIND_COUNT];
+PT_MARK("drain_begin");
+	const uint32_t total = uniform(sh.count[KIND_COUNT]);
 	if(total == 0) return;
-	for(uint32_t i = (uint32_t)lane; i < total; i += 64) {
-		uint32_t e = sh.pool[i];
-		uint32_t kind = (e >> 23) & 7u;
-		uint32_t base = kind == 0 ? off[0] : kind == 1 ? off[1] : kind == 2 ? off[2] : kind == 3 ? off[3] : kind == 4 ? off[4] : off[5];
-		sh.sorted[base + atomicAdd(&sh.fill[kind], 1u)] = e;
-	}
-	wave_sync();
-	// Few candidates: one chunk of mixed kinds costs less than a nearly empty chunk per kind.
-	if(total <= (uint32_t)COOP_MIX_ALL) {
-		for(uint32_t base = 0; base < total; base += 64) coop_chunk<KIND_MIXED>(sc, sh, base, total, lane);
+	if(total <= 64u) {
+		// one chunk of mixed kinds, whatever their order: straight from the pool
+		coop_chunk<KIND_MIXED>(sc, sh, sh.pool, 0, total, lane);
 	} else {
-		for(uint32_t base = off[0]; base < off[1]; base += 64) coop_chunk<KIND_SPHERE>(sc, sh, base, off[1], lane);
-		for(uint32_t base = off[1]; base < off[2]; base += 64) coop_chunk<KIND_BOX>(sc, sh, base, off[2], lane);
-		if(off[6] - off[2] <= (uint32_t)COOP_MIX_UNIT) {
-			for(uint32_t base = off[2]; base < off[6]; base += 64) coop_chunk<KIND_MIXED>(sc, sh, base, off[6], lane);
+		uint32_t off[KIND_COUNT + 1];
+		off[0] = 0;
+		#pragma unroll
+		for(int k = 0; k < KIND_COUNT; k++) off[k + 1] = off[k] + uniform(sh.count[k]);
+		for(uint32_t i = (uint32_t)lane; i < total; i += 64) {
+			uint32_t e = sh.pool[i];
+			uint32_t kind = (e >> 23) & 7u;
+			uint32_t base = kind == 0 ? off[0] : kind == 1 ? off[1] : kind == 2 ? off[2] : kind == 3 ? off[3] : kind == 4 ? off[4] : off[5];
+			sh.sorted[base + atomicAdd(&sh.fill[kind], 1u)] = e;
+		}
+		wave_sync();
+		// Few candidates: chunks of mixed kinds cost less than a nearly empty chunk per kind.
+		if(total <= (uint32_t)COOP_MIX_ALL) {
+			for(uint32_t base = 0; base < total; base += 64) coop_chunk<KIND_MIXED>(sc, sh, sh.sorted, base, total, lane);
 		} else {
-			for(uint32_t base = off[2]; base < off[3]; base += 64) coop_chunk<KIND_BOX_ROTATED>(sc, sh, base, off[3], lane);
-			for(uint32_t base = off[3]; base < off[4]; base += 64) coop_chunk<KIND_ELLIPSOID>(sc, sh, base, off[4], lane);
-			for(uint32_t base = off[4]; base < off[5]; base += 64) coop_chunk<KIND_CYLINDER>(sc, sh, base, off[5], lane);
-			for(uint32_t base = off[5]; base < off[6]; base += 64) coop_chunk<KIND_CONE>(sc, sh, base, off[6], lane);
+			for(uint32_t base = off[0]; base < off[1]; base += 64) coop_chunk<KIND_SPHERE>(sc, sh, sh.sorted, base, off[1], lane);
+			for(uint32_t base = off[1]; base < off[2]; base += 64) coop_chunk<KIND_BOX>(sc, sh, sh.sorted, base, off[2], lane);
+			if(off[6] - off[2] <= (uint32_t)COOP_MIX_UNIT) {
+				for(uint32_t base = off[2]; base < off[6]; base += 64) coop_chunk<KIND_MIXED>(sc, sh, sh.sorted, base, off[6], lane);
+			} else {
+				for(uint32_t base = off[2]; base < off[3]; base += 64) coop_chunk<KIND_BOX_ROTATED>(sc, sh, sh.sorted, base, off[3], lane);
+				for(uint32_t base = off[3]; base < off[4]; base += 64) coop_chunk<KIND_ELLIPSOID>(sc, sh, sh.sorted, base, off[4], lane);
+				for(uint32_t base = off[4]; base < off[5]; base += 64) coop_chunk<KIND_CYLINDER>(sc, sh, sh.sorted, base, off[5], lane);
+				for(uint32_t base = off[5]; base < off[6]; base += 64) coop_chunk<KIND_CONE>(sc, sh, sh.sorted, base, off[6], lane);
+			}
 		}
 	}
+PT_MARK("drain_tail");
 	if(lane < KIND_COUNT + 2) { sh.count[lane] = 0; sh.fill[lane] = 0; }
 	wave_sync();
 }
@@ -948,6 +992,7 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 #endif
 		if(lane == 0) PT_STAT(1, 1);
 		PT_TICK(t0);
+PT_MARK("seg_begin");
 		// ---- reset the wavefront's bins --------------------------------------------------------
 		if(lane < KIND_COUNT + 2) { sh.count[lane] = 0; sh.fill[lane] = 0; }
 		if(lane < COOP_HEAD_WORDS) sh.head[lane] = 0;
@@ -956,34 +1001,49 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 		sh.ncell[lane] = 0;
 		wave_sync();
 
+PT_MARK("walk_begin");
 		// ---- walk: note the non-empty cells of the next COOP_CELLS steps ---------------------------
 		// A probe copy of the walker runs through the whole segment first, so the list bounds of
 		// all its cells are fetched in one memory round trip.
-		int recorded = 0, m = 0;
-		bool more = true;
-		WalkLite probe;
-		probe.cx = st.cx; probe.cy = st.cy; probe.cz = st.cz; probe.tx = st.tx; probe.ty = st.ty; probe.tz = st.tz;
-		{
+		// The steps are written without branches: which axis advances is three comparisons, and everything that
+		// follows from it a select (the ties of spatialGridTraverseNext: x<y ? (x<z ? X : Z) : (y<z ? Y : Z)).
+		int m = 0;                            // cells of this segment that lie inside the grid
+		bool more = walking;                  // the probe stands on a cell of the grid
+		int cx = st.cx, cy = st.cy, cz = st.cz;
+		float tx = st.tx, ty = st.ty, tz = st.tz;
+		uint32_t cc[COOP_CELLS], ka[COOP_CELLS], kb[COOP_CELLS], fc[COOP_CELLS];
+		#pragma unroll
+		for(int j = 0; j < COOP_CELLS; j++) { cc[j] = 0; ka[j] = 0; kb[j] = 0; fc[j] = 7; }
+		if(walking) {
 			V3 from, dir;
 			get6(sh.ray[lane], from, dir);
-			probe.sx = sign_of(dir.x); probe.sy = sign_of(dir.y); probe.sz = sign_of(dir.z);
-			probe.dx = st.dx; probe.dy = st.dy; probe.dz = st.dz;
-		}
-		uint32_t cc[COOP_CELLS], ka[COOP_CELLS], kb[COOP_CELLS];
-		#pragma unroll
-		for(int j = 0; j < COOP_CELLS; j++) { cc[j] = 0; ka[j] = 0; kb[j] = 0; }
-		if(walking) {
+			const int sx = sign_of(dir.x), sy = sign_of(dir.y), sz = sign_of(dir.z);
+			// the face a step enters the next cell through: -x +x -y +y -z +z, 7 for the cell the segment starts in
+			const uint32_t fx = (uint32_t)sx >> 31, fy = 2u + ((uint32_t)sy >> 31), fz = 4u + ((uint32_t)sz >> 31);
+			const int nx = sc.grid.cnt[0], ny = sc.grid.cnt[1], nz = sc.grid.cnt[2];
+			uint32_t face = 7;
 			int pc[COOP_CELLS];
 			#pragma unroll
 			for(int j = 0; j < COOP_CELLS; j++) {
-				pc[j] = 0;
-				if(more) { pc[j] = lite_cell(sc.grid, probe); cc[j] = pack_cell(probe.cx, probe.cy, probe.cz); m = j + 1; more = lite_next(sc.grid, probe); }
+				pc[j] = more ? (cz * ny + cy) * nx + cx : 0;
+				cc[j] = pack_cell(cx, cy, cz);
+				fc[j] = face;
+				m += more ? 1 : 0;
+				const bool xy = tx < ty, xz = tx < tz, yz = ty < tz;
+				const bool ax = xy && xz, ay = !xy && yz;
+				const bool az = !(ax || ay);
+				face = ax ? fx : ay ? fy : fz;
+				cx += ax ? sx : 0; cy += ay ? sy : 0; cz += az ? sz : 0;
+				const float ux = tx + st.dx, uy = ty + st.dy, uz = tz + st.dz;
+				tx = ax ? ux : tx; ty = ay ? uy : ty; tz = az ? uz : tz;
+				more = more && (uint32_t)cx < (uint32_t)nx && (uint32_t)cy < (uint32_t)ny && (uint32_t)cz < (uint32_t)nz;
 			}
 			#pragma unroll
 			for(int j = 0; j < COOP_CELLS; j++) { ka[j] = sc.cell_start[pc[j]]; kb[j] = sc.cell_start[pc[j] + 1]; }
 		}
 		PT_TOCK_ISSUED(sh, 6, t0);
 		PT_TOCK_LANDED(sh, 7, t0);
+PT_MARK("walk_stepped");
 		// Descriptors and sequence positions are dealt ray by ray: two wave prefix sums (lists and entries per lane, in
 		// registers) give every lane the slot and the position its first list starts at, its other lists follow.  The
 		// lanes are served in an order that starts one lane later every segment, so no lane is last for ever.  A list is
@@ -993,7 +1053,7 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 		uint32_t my_lists = 0, my_entries = 0;
 		#pragma unroll
 		for(int j = 0; j < COOP_CELLS; j++) {
-			const uint32_t c = (walking && j < m) ? kb[j] - ka[j] : 0u;
+			const uint32_t c = j < m ? kb[j] - ka[j] : 0u;
 			my_lists += c > 0 ? 1u : 0u;
 			my_entries += c;
 		}
@@ -1008,31 +1068,29 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 			slot = (upto_l - my_lists) + (early ? 0u - skipped_l : all_lists - skipped_l);
 			start = (upto_e - my_entries) + (early ? 0u - skipped_e : all_entries - skipped_e);
 		}
-		bool open = walking, turned_away = false;
+PT_MARK("walk_dealt");
+		// A lane's lists follow one another from its slot and position.  The first list that finds no descriptor free or
+		// would start past the bitmap is turned away, and with it everything behind it (slot and position stay where they
+		// are, so what follows meets the same refusal); its cell and the cells after it wait for the next segment.
+		int turned_at = COOP_CELLS;
 		#pragma unroll
 		for(int j = 0; j < COOP_CELLS; j++) {
-			const bool here = open && j < m;
-			const uint32_t c = here ? kb[j] - ka[j] : 0u;
-			if(c > 0) {
-				if(slot >= (uint32_t)COOP_DESCS || start >= COOP_SEQ_MAX) {
-					open = false;          // this cell and the ones after it wait for the next segment; slot and start stay at the refusal
-					turned_away = true;
-				} else {
-					sh.desc_k0[slot] = ka[j];
-					// the face the ray came in through, from the coordinate that changed: -x +x -y +y -z +z
-					uint32_t face = 7;
-					if(j > 0) {
-						const int step = (int)cc[j] - (int)cc[j > 0 ? j - 1 : 0];
-						face = step == 1 ? 0u : step == -1 ? 1u : step == 1024 ? 2u : step == -1024 ? 3u : step > 0 ? 4u : 5u;
-					}
-					sh.desc_at[slot] = (start << 12) | (uint32_t)lane | ((uint32_t)j << 6) | (face << 9);
-					atomicOr(&sh.head[start >> 5], 1u << (start & 31u));       // start < COOP_SEQ_MAX for every list taken
-					slot += 1u;
-					start += c;
-				}
+			const uint32_t c = j < m ? kb[j] - ka[j] : 0u;
+			const bool fits = slot < (uint32_t)COOP_DESCS && start < COOP_SEQ_MAX;
+			const bool take = c > 0 && fits;
+			turned_at = (c > 0 && !fits) ? imin(turned_at, j) : turned_at;
+			if(take) {
+				sh.desc_k0[slot] = ka[j];
+				sh.desc_at[slot] = (start << 12) | (uint32_t)lane | ((uint32_t)j << 6) | (fc[j] << 9);
+				atomicOr(&sh.head[start >> 5], 1u << (start & 31u));       // start < COOP_SEQ_MAX for every list taken
 			}
-			if(here && open) { sh.cells[j][lane] = cc[j]; recorded = j + 1; }
+			slot += take ? 1u : 0u;
+			start += take ? c : 0u;
+			sh.cells[j][lane] = cc[j];             // all of them: what lies past the recorded ones is never looked at
 		}
+		const bool turned_away = turned_at < COOP_CELLS;
+		const int recorded = imin(m, turned_at);
+PT_MARK("walk_placed");
 		// the first refusal in serving order ends the sequence: what was placed before it is contiguous from zero
 		uint32_t ndesc = all_lists, total = all_entries;
 		{
@@ -1051,6 +1109,7 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 		wave_sync();
 		PT_TOCK(sh, 10, t0);
 
+PT_MARK("expand_begin");
 		// ---- expand: the lists of all lanes as one sequence, 64 entries per round ------------------
 		// Which list an entry position belongs to: descriptors are in position order, so it is the number of
 		// list heads at or before the position, less one - a prefix count per bitmap word plus a popcount.
@@ -1064,7 +1123,9 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 			if(lane < COOP_HEAD_WORDS) sh.rank0[lane] = (uint16_t)(upto - mine);
 		}
 		wave_sync();
+PT_MARK("expand_loop");
 		for(uint32_t base = 0; base < total; base += 64 * COOP_ITEMS) {
+PT_MARK("trip_begin");
 			// COOP_ITEMS independent items per lane and trip, so their LDS and memory round trips overlap
 			uint32_t item[COOP_ITEMS], d[COOP_ITEMS];
 			#pragma unroll
@@ -1076,6 +1137,7 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 				const uint32_t heads = sh.head[pos >> 5] & (0xffffffffu >> (31u - (pos & 31u)));
 				d[u] = (past && item[u] < total) ? ndesc - 1u : (uint32_t)sh.rank0[pos >> 5] + (uint32_t)__popc(heads) - 1u;
 			}
+PT_MARK("trip_ranked");
 			uint32_t who[COOP_ITEMS], id[COOP_ITEMS];
 			v4f e[COOP_ITEMS];
 			bool live[COOP_ITEMS];
@@ -1089,6 +1151,7 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 			}
 			PT_TOCK_ISSUED(sh, 11, t0);
 			PT_TOCK_LANDED(sh, 8, t0);
+PT_MARK("trip_loaded");
 			#pragma unroll
 			for(int u = 0; u < COOP_ITEMS; u++) {
 				if(live[u]) {
@@ -1112,6 +1175,7 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 					}
 				}
 			}
+PT_MARK("trip_filtered");
 			wave_sync();
 			if(uniform(sh.count[KIND_COUNT]) > (uint32_t)(COOP_POOL - 64 * COOP_ITEMS)) {
 				PT_TOCK(sh, 11, t0);
@@ -1121,10 +1185,12 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 		}
 		PT_TOCK(sh, 11, t0);
 
+PT_MARK("expand_end");
 		// ---- test what is left in the pool ------------------------------------------------------------
 		coop_drain(sc, sh, lane);
 		PT_TOCK(sh, 12, t0);
 
+PT_MARK("verdict_begin");
 		// ---- verdict: every list of every recorded cell has been tested ------------------------------
 		if(walking) {
 			unsigned long long key = recorded > 0 ? sh.best[lane] : COOP_NONE;
@@ -1136,14 +1202,22 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 				if(!more) walking = false;   // the ray has left the grid; else the probe stands on the first cell of the next segment
 			} else {
 				// stopped early: resume at the first cell not recorded
+				WalkLite probe;
+				V3 from, dir;
+				get6(sh.ray[lane], from, dir);
+				probe.sx = sign_of(dir.x); probe.sy = sign_of(dir.y); probe.sz = sign_of(dir.z);
+				probe.dx = st.dx; probe.dy = st.dy; probe.dz = st.dz;
 				probe.cx = st.cx; probe.cy = st.cy; probe.cz = st.cz; probe.tx = st.tx; probe.ty = st.ty; probe.tz = st.tz;
 				for(int j = 0; j < recorded; j++) lite_next(sc.grid, probe);
+				cx = probe.cx; cy = probe.cy; cz = probe.cz; tx = probe.tx; ty = probe.ty; tz = probe.tz;
 			}
-			st.cx = probe.cx; st.cy = probe.cy; st.cz = probe.cz; st.tx = probe.tx; st.ty = probe.ty; st.tz = probe.tz;
+			st.cx = cx; st.cy = cy; st.cz = cz; st.tx = tx; st.ty = ty; st.tz = tz;
 		}
 		PT_TOCK(sh, 13, t0);
+PT_MARK("verdict_end");
 		if(__popcll(__ballot(walking)) < COOP_MIN_WALKING) break;
 	}
+PT_MARK("cast_tail");
 	st.walking = walking;
 	done = active && !walking;
 	if(result != 0) surf = surface_of(sc, result - 1);

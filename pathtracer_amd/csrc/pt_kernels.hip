@@ -43,7 +43,9 @@ __device__ __forceinline__ int lanes_below(uint64_t mask) {
 template <bool THROUGH>
 __device__ __forceinline__ void store_sum(const ptl::TraceJob& job, float4* at, float x, float y, float z) {
 	const v4f v = { x, y, z, __uint_as_float(job.serial) };
-	if(THROUGH) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(at), "v"(v) : "memory");
+	// The compiler cannot see that this is a store of more than eight bytes: an instruction that overwrites one of its four
+	// data registers must keep two wait states' distance (on this chip), so they are part of the statement.
+	if(THROUGH) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(at), "v"(v) : "memory");
 	else *at = make_float4(v.x, v.y, v.z, v.w);
 }
 
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIM
 		// ---- stage 0: lanes without a pixel draw one from the wave's pool -------------------
 		// (Making lanes wait until several ask together was measured: the idle lanes cost more than
 		// the hand-outs saved.)
+PT_MARK("loop_begin");
 		uint64_t want = __ballot(state == NEED_PIXEL);
 		while(want != 0) {
 			if(pool_pos == kGroup) {
@@ -263,10 +266,12 @@ __global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIM
 			pool_pos += asked < avail ? asked : avail;
 			want = __ballot(state == NEED_PIXEL);
 		}
+PT_MARK("handed_out");
 		if(dry && state == NEED_PIXEL) state = RETIRED;
 		if(__ballot(state != RETIRED) == 0) break;
 		PT_TOCK(coop, MODE == CAST_GRID_COOP ? 15 : 10, t_loop);   // non-cooperative variants: slot 10 = pixel hand-out, 11 = camera ray, 14 = cast, 12 = shade and pixel write
 
+PT_MARK("camera_begin");
 		// ---- stage 1: generate the camera ray of the next sample (code/raycast.cpp:1059-1090) ---
 		if(state == NEED_PATH) {
 			v2f s = sc.samples[sample_base + si];
@@ -281,6 +286,7 @@ __global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIM
 			state = IN_FLIGHT;
 		}
 
+PT_MARK("camera_end");
 		// ---- stage 2+3: extend one ray and shade the hit (code/raycast.cpp:1092-1261) ---------
 		const bool flying = state == IN_FLIGHT;
 		V3 hp = v3(0, 0, 0), hn = v3(0, 0, 0);
@@ -289,6 +295,7 @@ __global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIM
 		int id = 0;
 		bool landed = flying;
 		PT_TOCK(coop, MODE == CAST_GRID_COOP ? 15 : 11, t_loop);
+PT_MARK("cast_begin");
 		if(MODE == CAST_GRID_COOP) {
 			// the whole wavefront takes part; lanes whose walk is not over yet stay in flight and resume
 			id = cast_grid_coop(sc, coop, lane, flying, fresh, walk_state, rp, rd, hp, hn, surf, landed);
@@ -302,6 +309,7 @@ __global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIM
 			}
 			PT_TOCK(coop, 14, t_loop);
 		}
+PT_MARK("cast_end");
 		casts += (uint32_t)__popcll(__ballot(landed));
 		if(landed) {
 			bool alive = shade<FEAT>(sc, fr, id, surf, hp, hn, bounce, rp, rd, att, col, rng);
@@ -316,6 +324,7 @@ __global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIM
 				}
 			}
 		}
+PT_MARK("shade_end");
 		PT_TOCK(coop, MODE == CAST_GRID_COOP ? 15 : 12, t_loop);
 	}
 
