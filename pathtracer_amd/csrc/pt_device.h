@@ -416,47 +416,113 @@ PT_DEV float intersect_kind(const GeoRef& g, v4f p0, v4f p3, V3 rp, V3 rd, V3& p
 	return distance;
 }
 
-// All six kinds in one body, for a wavefront whose lanes hold candidates of different kinds: the
-// kinds that work in the entity's unit space (rotated box, ellipsoid, cylinder, cone) share the
-// transformation in and out, which is most of their cost; only the canonical-shape test in the
-// middle diverges.  Every lane runs exactly the operation sequence of its intersect_kind variant.
+// Cylinder and cone in one body (hit_cylinder, hit_cone): both solve a quadratic in the entity's unit space and differ in
+// its coefficients and in what happens at the ends of the shape.  Every lane computes exactly the operations of its own
+// shape, in its order; what the two have in common (discriminant, root, the two quotients, the plane crossings, the side
+// normal) is executed once for both.
+PT_DEV float hit_round(bool cone, V3 p, V3 d, V3& pos, V3& nrm) {
+	const float pz = cone ? p.z - 0.5f : p.z;
+	const float dd = d.x * d.x + d.y * d.y;
+	const float a = cone ? dd - d.z * d.z : dd;
+	const float b = cone ? 2 * p.x * d.x + 2 * p.y * d.y - 2 * pz * d.z : 2 * (p.x * d.x + p.y * d.y);
+	const float pp = p.x * p.x + p.y * p.y;
+	const float c = cone ? pp - pz * pz : pp - 1;
+	const float disc = b * b - 4 * a * c;
+	if(disc < 0) return -1;
+	const float root = sq_root(disc);
+	float t1 = (-b + root) / (2 * a);
+	float t2 = (-b - root) / (2 * a);
+	const float z1 = pz + d.z * t1;
+	const float z2 = pz + d.z * t2;
+	const float t_low = (-1 - pz) / d.z;      // the plane z = -1: the cylinder's bottom cap, the cone's base
+	const float t_high = (1 - pz) / d.z;      // the cylinder's top cap
+	int k1 = 0, k2 = 0;                       // what a root stands for: 0 side, 1 top cap, 2 bottom cap or base, 3 nothing
+	if(cone) {
+		if(z1 > 0 || z1 < -1) k1 = 2;
+		if(z2 > 0 || z2 < -1) k2 = 2;
+		if(k1 == 2 && k2 == 2) return -1;
+		if(k1 == 2) t1 = t_low;
+		else if(k2 == 2) t2 = t_low;
+	} else {
+		if(z1 > 1) { if(z2 <= 1) { k1 = 1; t1 = t_high; } else k1 = 3; }
+		else if(z1 < -1) { if(z2 >= -1) { k1 = 2; t1 = t_low; } else k1 = 3; }
+		if(z2 > 1) { if(z1 <= 1) { k2 = 1; t2 = t_high; } else k2 = 3; }
+		else if(z2 < -1) { if(z1 >= -1) { k2 = 2; t2 = t_low; } else k2 = 3; }
+		if(k1 == 3 && k2 == 3) return -1;
+	}
+	if(t1 < 0 && t2 < 0) return -1;
+	float distance = tmin(t1, t2);
+	if(distance < 0) distance = tmax(t1, t2);
+	pos = v3(p.x, p.y, cone ? pz + 0.5f : p.z) + d * distance;
+	const int k = distance == t1 ? k1 : k2;
+	if(k == 0) {
+		if(pos.x == 0 && pos.y == 0) nrm = cone ? v3(0, 0, 1) : v3(1, 0, 0);
+		else {
+			const V3 n = normalise(v3(pos.x, pos.y, 0));
+			nrm = n;
+			if(cone) nrm = normalise(v3(n.x, n.y, 1));
+		}
+	}
+	else nrm = (!cone && k == 1) ? v3(0, 0, 1) : v3(0, 0, -1);
+	return distance;
+}
+
+// All six kinds in one body, for a wavefront whose lanes hold candidates of different kinds.  The kinds that work in the
+// entity's unit space (rotated box, ellipsoid, cylinder, cone) share the transformation in and out; both boxes share the
+// slab test, both spheres the sphere test, cylinder and cone the quadratic - with their own operands: a world-space shape
+// takes the ray as it is, a unit-space one the transformed ray and the canonical shape (a centre of zero leaves every
+// difference and sum as it is: x - 0 and 0 + x are x, 0 - x is the box's lower corner as hit_box computes it).  Every lane
+// runs exactly the operation sequence of its intersect_kind variant.
 constexpr int KIND_MIXED = KIND_COUNT;
 PT_DEV float intersect_mixed(int kind, const GeoRef& g, v4f p0, v4f p3, V3 rp, V3 rd, V3& pos, V3& nrm) {
-	V3 opos = v3(p0.x, p0.y, p0.z);
-	V3 dim = v3(p3.x, p3.y, p3.z);
-	if(kind == KIND_SPHERE) return hit_sphere(rp, rd, opos, p0.w, pos, nrm);
-	if(kind == KIND_BOX) {
-		v4f lo = g.plane(G_BOX_LO), hi = g.plane(G_BOX_HI);
-		return hit_slabs(rp, rd, v3(lo.x, lo.y, lo.z), v3(hi.x, hi.y, hi.z), pos, nrm);
-	}
+	const V3 opos = v3(p0.x, p0.y, p0.z);
+	const V3 dim = v3(p3.x, p3.y, p3.z);
 	const bool isbox = kind == KIND_BOX_ROTATED;
-	const bool turned = isbox || ((__float_as_int(p3.w) >> 8) & FLAG_ROTATED);
-	v4f si = g.plane(G_SCALEINV);
-	V3 sinv = v3(si.x, si.y, si.z);
-	V3 a = rp - opos;
-	V3 b = isbox ? a + rd : rd;
-	if(turned) {
-		v4f ri = g.plane(G_ROTINV);
-		a = rotate(ri, a);
-		b = rotate(ri, b);
+	const bool unit = kind >= KIND_BOX_ROTATED;
+	const bool turned = isbox || (unit && ((__float_as_int(p3.w) >> 8) & FLAG_ROTATED));
+	V3 a = rp, ld = rd, sinv = v3(1, 1, 1);
+	if(unit) {
+		const v4f si = g.plane(G_SCALEINV);
+		sinv = v3(si.x, si.y, si.z);
+		a = rp - opos;
+		V3 b = isbox ? a + rd : rd;
+		if(turned) {
+			const v4f ri = g.plane(G_ROTINV);
+			a = rotate(ri, a);
+			b = rotate(ri, b);
+		}
+		V3 din;
+		if(isbox) din = b - a;
+		else { a = a * sinv; din = b * sinv; }
+		ld = normalise(din);
 	}
-	V3 din;
-	if(isbox) din = b - a;
-	else { a = a * sinv; din = b * sinv; }
-	V3 ld = normalise(din);
 	float distance;
-	if(isbox) distance = hit_box(a, ld, v3(0, 0, 0), dim, pos, nrm);
-	else if(kind == KIND_ELLIPSOID) distance = hit_sphere(a, ld, v3(0, 0, 0), 0.5f, pos, nrm);
-	else if(kind == KIND_CYLINDER) distance = hit_cylinder(a, ld, pos, nrm);
-	else distance = hit_cone(a, ld, pos, nrm);
-	if(distance != -1) {
+	if(kind == KIND_BOX || isbox) {
+		V3 bmin, bmax;
+		if(isbox) {
+			const V3 half = dim * 0.5f;            // the same floats as dim / 2
+			bmin = v3(0, 0, 0) - half;
+			bmax = v3(0, 0, 0) + half;
+		} else {
+			const v4f lo = g.plane(G_BOX_LO), hi = g.plane(G_BOX_HI);
+			bmin = v3(lo.x, lo.y, lo.z);
+			bmax = v3(hi.x, hi.y, hi.z);
+		}
+		distance = hit_slabs(a, ld, bmin, bmax, pos, nrm);
+	} else if(kind == KIND_SPHERE || kind == KIND_ELLIPSOID) {
+		const bool even = kind == KIND_SPHERE;
+		distance = hit_sphere(a, ld, even ? opos : v3(0, 0, 0), even ? p0.w : 0.5f, pos, nrm);
+	} else {
+		distance = hit_round(kind == KIND_CONE, a, ld, pos, nrm);
+	}
+	if(unit && distance != -1) {
 		if(!isbox) {
-			v4f sc4 = g.plane(G_SCALE);
+			const v4f sc4 = g.plane(G_SCALE);
 			pos = pos * v3(sc4.x, sc4.y, sc4.z);
 			nrm = nrm * sinv;
 		}
 		if(turned) {
-			v4f r = g.plane(G_ROT);
+			const v4f r = g.plane(G_ROT);
 			pos = rotate(r, pos);
 			nrm = rotate(r, nrm);
 		}

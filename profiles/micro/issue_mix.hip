@@ -41,6 +41,23 @@
 	"ds_read_b32 %7, %10\n v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n" \
 	"v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n s_waitcnt lgkmcnt(0)\n v_mul_f32 %7, %7, %8\n"
 
+// integer multiplies: full 32-bit, 24-bit, and the 64-bit multiply-add PCG32's state update is made of
+#define VI8 \
+	"v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n" \
+	"v_mul_lo_u32 %4, %4, %8\n v_mul_lo_u32 %5, %5, %8\n v_mul_lo_u32 %6, %6, %8\n v_mul_lo_u32 %7, %7, %8\n"
+#define VU8 \
+	"v_mul_u32_u24 %0, %0, %8\n v_mul_u32_u24 %1, %1, %8\n v_mul_u32_u24 %2, %2, %8\n v_mul_u32_u24 %3, %3, %8\n" \
+	"v_mul_u32_u24 %4, %4, %8\n v_mul_u32_u24 %5, %5, %8\n v_mul_u32_u24 %6, %6, %8\n v_mul_u32_u24 %7, %7, %8\n"
+#define VQ8 \
+	"v_mad_u64_u32 v[20:21], vcc, %0, %8, v[20:21]\n v_mad_u64_u32 v[22:23], vcc, %1, %8, v[22:23]\n v_mad_u64_u32 v[24:25], vcc, %2, %8, v[24:25]\n v_mad_u64_u32 v[26:27], vcc, %3, %8, v[26:27]\n" \
+	"v_mad_u64_u32 v[20:21], vcc, %4, %8, v[20:21]\n v_mad_u64_u32 v[22:23], vcc, %5, %8, v[22:23]\n v_mad_u64_u32 v[24:25], vcc, %6, %8, v[24:25]\n v_mad_u64_u32 v[26:27], vcc, %7, %8, v[26:27]\n"
+#define VF8 \
+	"v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n" \
+	"v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+#define VS8Q \
+	"v_sqrt_f32 %0, %0\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n" \
+	"v_sqrt_f32 %4, %4\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n"
+
 #define KERNEL(NAME, BODY) \
 __global__ __launch_bounds__(64) void NAME(float* out, int iters, float seed) { \
 	__shared__ float lds[64]; \
@@ -49,7 +66,7 @@ __global__ __launch_bounds__(64) void NAME(float* out, int iters, float seed) { 
 	const float m = 1.0000001f, big = 1e30f; \
 	const uint32_t at = threadIdx.x * 4; \
 	for(int i = 0; i < iters; i++) { \
-		asm volatile(BODY BODY BODY BODY : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(m), "v"(big), "v"(at) : "vcc", "s20", "s21", "s22", "s23", "s24", "s25", "memory"); \
+		asm volatile(BODY BODY BODY BODY : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(m), "v"(big), "v"(at) : "vcc", "s20", "s21", "s22", "s23", "s24", "s25", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "memory"); \
 	} \
 	float s = a + b + c + d + e + f + g + h; \
 	if(s == 12345.678f) out[0] = s; \
@@ -64,6 +81,11 @@ KERNEL(k_vd, VD8)
 KERNEL(k_vd2, VD4x2)
 KERNEL(k_vt, VT8)
 KERNEL(k_vl, VL8)
+KERNEL(k_vi, VI8)
+KERNEL(k_vu, VU8)
+KERNEL(k_vq, VQ8)
+KERNEL(k_vf, VF8)
+KERNEL(k_vsq, VS8Q)
 
 typedef void (*kern_t)(float*, int, float);
 static void run(const char* name, kern_t kernel, int valu_per_body, int waves_per_simd, float* d) {
@@ -88,7 +110,7 @@ static void run(const char* name, kern_t kernel, int valu_per_body, int waves_pe
 int main() {
 	float* d;
 	(void)hipMalloc(&d, 256);
-	for(int w : { 1, 2, 4, 5, 8 }) {
+	for(int w : { 1, 4, 8 }) {
 		run("8 vector, independent", k_v, 8, w, d);
 		run("8 vector + 8 scalar adds", k_vs, 8, w, d);
 		run("8 vector + 8 s_nop 0", k_vn, 8, w, d);
@@ -98,6 +120,11 @@ int main() {
 		run("8 vector, two dependent chains", k_vd2, 8, w, d);
 		run("6 vector + 2 v_rcp", k_vt, 8, w, d);
 		run("8 vector + LDS read and wait", k_vl, 8, w, d);
+		run("8 v_mul_lo_u32", k_vi, 8, w, d);
+		run("8 v_mul_u32_u24", k_vu, 8, w, d);
+		run("8 v_mad_u64_u32", k_vq, 8, w, d);
+		run("8 v_fma_f32", k_vf, 8, w, d);
+		run("6 vector + 2 v_sqrt", k_vsq, 8, w, d);
 	}
 	return 0;
 }
