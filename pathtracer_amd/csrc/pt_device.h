@@ -1181,11 +1181,7 @@ PT_MARK("expand_begin");
 		// list heads at or before the position, less one - a prefix count per bitmap word plus a popcount.
 		{
 			const uint32_t mine = lane < COOP_HEAD_WORDS ? (uint32_t)__popc(sh.head[lane < COOP_HEAD_WORDS ? lane : 0]) : 0u;
-			uint32_t upto = mine;
-			for(int off = 1; off < COOP_HEAD_WORDS; off <<= 1) {
-				const uint32_t below = __shfl_up(upto, off, 64);
-				if(lane >= off) upto += below;
-			}
+			const uint32_t upto = wave_inclusive_sum(mine);
 			if(lane < COOP_HEAD_WORDS) sh.rank0[lane] = (uint16_t)(upto - mine);
 		}
 		wave_sync();

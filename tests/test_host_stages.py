@@ -178,3 +178,19 @@ def test_host_stages_under_sanitizers(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
     assert r.stdout.startswith("checksum")
+
+
+def test_write_through_store_keeps_its_wait_states():
+    """The one inline-assembly statement of the library is a 16-byte store the compiler cannot see into: the two wait
+    states that must separate it from an instruction overwriting its data registers have to be part of the statement."""
+    import re
+    src = open(os.path.join(ROOT, "pathtracer_amd", "csrc", "pt_kernels.hip")).read()
+    stores = re.findall(r'asm volatile\("(global_store[^"]*)"', src)
+    assert stores, "the write-through store is gone: drop this test with it"
+    for s in stores:
+        assert re.search(r"global_store_dwordx4 [^\\]*\\n\\ts_nop 1$", s), s
+    # nothing else in the device sources issues memory instructions behind the compiler's back
+    for name in os.listdir(os.path.join(ROOT, "pathtracer_amd", "csrc")):
+        text = open(os.path.join(ROOT, "pathtracer_amd", "csrc", name)).read()
+        for body in re.findall(r'asm volatile\("([^"]*)"', text):
+            assert not re.search(r"\b(global|flat|buffer|scratch|ds)_", body) or body in stores, (name, body)
