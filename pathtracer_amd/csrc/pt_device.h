@@ -129,9 +129,8 @@ PT_DEV float tmax(float a, float b) { return a >= b ? a : b; }
 PT_DEV float clamp_hi(float a, float hi) { return a > hi ? hi : a; }
 PT_DEV V3 clamp_hi(V3 a, float hi) { return v3(clamp_hi(a.x, hi), clamp_hi(a.y, hi), clamp_hi(a.z, hi)); }
 PT_DEV float blend(float t, float a, float b) {             // lerpCheck, code/rt_math.cpp:222-226
-	if(t == 0) return a;
-	else if(t == 1) return b;
-	else return a + t * (b - a);
+	const float between = a + t * (b - a);
+	return t == 0 ? a : (t == 1 ? b : between);
 }
 PT_DEV V3 mirror(V3 dir, V3 n) {                            // reflectVector, code/rt_math.cpp:2405-2408
 	float k = 2 * dot(dir, n);
@@ -221,8 +220,9 @@ PT_DEV bool touches_sphere(V3 lp, V3 ld, V3 sp, float sr) {  // lineSphereCollis
 	// than a margin far above their rounding errors, the answer is known without the roots.
 	float margin = 1e-5f * (d * d + ll + rr);
 	float b_est = d * d - ll + rr;
-	const bool clear_miss = b_est < -margin || (d > 0 && ll - rr > margin);
-	const bool clear_hit = b_est > margin && (d < 0 || rr - ll > margin);
+	// (plain & and |: every operand is a comparison of values at hand, cheaper to evaluate than to branch around)
+	const bool clear_miss = (b_est < -margin) | ((d > 0) & (ll - rr > margin));
+	const bool clear_hit = (b_est > margin) & ((d < 0) | (rr - ll > margin));
 	bool touches = clear_hit;
 	if(__ballot(!clear_miss && !clear_hit) != 0) {            // wave-uniform: the roots are skipped only if no lane needs them
 		float l = sqrtf(ll);                                  // length(lp): the same sum of squares
@@ -249,13 +249,12 @@ PT_DEV float hit_slabs(V3 lp, V3 ld, V3 bmin, V3 bmax, V3& pos, V3& nrm) {
 	if(tn > tf) return -1;
 	float distance = tn < 0 ? tf : tn;
 	pos = lp + ld * distance;
-	if(distance == t1) nrm = v3(-1, 0, 0);
-	else if(distance == t2) nrm = v3(1, 0, 0);
-	else if(distance == t3) nrm = v3(0, -1, 0);
-	else if(distance == t4) nrm = v3(0, 1, 0);
-	else if(distance == t5) nrm = v3(0, 0, -1);
-	else if(distance == t6) nrm = v3(0, 0, 1);
-	else nrm = v3(0, 0, 0);
+	// the first of t1 .. t6 that equals the distance names the face (selects, not a chain of branches)
+	const bool f1 = distance == t1, f2 = distance == t2, f3 = distance == t3, f4 = distance == t4, f5 = distance == t5, f6 = distance == t6;
+	const bool on_x = f1 | f2, on_xy = on_x | f3 | f4;
+	nrm.x = f1 ? -1.0f : (f2 ? 1.0f : 0.0f);
+	nrm.y = on_x ? 0.0f : (f3 ? -1.0f : (f4 ? 1.0f : 0.0f));
+	nrm.z = on_xy ? 0.0f : (f5 ? -1.0f : (f6 ? 1.0f : 0.0f));
 	return distance;
 }
 PT_DEV float hit_box(V3 lp, V3 ld, V3 bpos, V3 bdim, V3& pos, V3& nrm) {
