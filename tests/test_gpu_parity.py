@@ -231,6 +231,19 @@ def test_partition_invariance(gpu):
         assert (bits(img) == bits(whole)).all(), parts
 
 
+@pytest.mark.parametrize("name", ["default", "default_grid", "glass", "dense2k", "small_mixed"])
+def test_both_store_variants_of_the_trace_kernel_agree(gpu, name):
+    """An asynchronous render (pt_render_start) runs the kernel twin whose range sums go through the caches to memory, a
+    resident-scene trace (pt_trace) the plain one: same image, bit for bit, for every cast variant."""
+    world, objs = CASES[name][0]()
+    st = settings_for(name, 168, 93, 16, 8)
+    through = gpu.render(world, objs, st).copy()
+    gpu.prepare(world, objs, st)
+    gpu.trace()
+    plain = gpu.download()
+    assert (bits(through) == bits(plain)).all()
+
+
 def test_assemble_on_device(gpu):
     """The multi-GPU data flow on one GPU: every partition traced into a caller-owned device buffer
     (as bench.py does with torch tensors) on a caller-owned stream, buffers side by side as after the
