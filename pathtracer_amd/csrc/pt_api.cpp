@@ -259,7 +259,7 @@ int prepare(pt_ctx* c) {
 
 	// one 128-byte record of eight float4 per entity (layout documented in pt_device.h)
 	const size_t np = (size_t)(n > 0 ? n : 1);
-	std::vector<float> geo(np * 8 * 4, 0.0f);
+	std::vector<float> geo(np * ptl::REC_STRIDE * 4, 0.0f);
 	int features = 0;          // what the entities need of a kernel variant: 1 unit-space kinds, 2 glass, 4 roughness (FEAT_* in pt_device.h)
 	for(int i = 0; i < n; i++) {
 		const float* r = rec.data() + (size_t)i * PT_F_STRIDE;
@@ -273,7 +273,7 @@ int prepare(pt_ctx* c) {
 		int32_t tf = type | (flags << 8);
 		float tf_bits;
 		memcpy(&tf_bits, &tf, 4);
-		auto slot = [&](int p) { return geo.data() + ((size_t)i * 8 + (size_t)p) * 4; };
+		auto slot = [&](int p) { return geo.data() + ((size_t)i * ptl::REC_STRIDE + (size_t)p) * 4; };
 		float* g0 = slot(ptl::REC_POS); g0[0] = r[PT_F_POS]; g0[1] = r[PT_F_POS + 1]; g0[2] = r[PT_F_POS + 2]; g0[3] = r[PT_F_BRADIUS];
 		memcpy(slot(ptl::REC_ROT), r + PT_F_ROT, 16);
 		memcpy(slot(ptl::REC_ROTINV), r + PT_F_ROTINV, 16);

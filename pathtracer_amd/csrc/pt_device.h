@@ -175,7 +175,7 @@ PT_DEV uint32_t rng_bounded(Rng& r) {
 // An entity is one 128-byte record of eight v4f (one cache line, so a lane that tests an entity touches one line, and a
 // wave-uniform index turns into wide scalar loads); the slots and their order are ptl::REC_* (pt_launch.h).
 enum { G_POS = ptl::REC_POS, G_ROT = ptl::REC_ROT, G_ROTINV = ptl::REC_ROTINV, G_DIM = ptl::REC_DIM, G_SCALE = ptl::REC_SCALE,
-       G_SCALEINV = ptl::REC_SCALEINV, M_COLOR = ptl::REC_COLOR, M_EMIT = ptl::REC_EMIT, G_SLOTS = ptl::REC_SLOTS };
+       G_SCALEINV = ptl::REC_SCALEINV, M_COLOR = ptl::REC_COLOR, M_EMIT = ptl::REC_EMIT, G_SLOTS = ptl::REC_STRIDE };
 // the corners of an unrotated box take the place of the two slots it never reads
 enum { G_BOX_LO = ptl::REC_ROTINV, G_BOX_HI = ptl::REC_SCALEINV };
 enum { FLAG_ROTATED = 1, FLAG_EVEN = 2 };

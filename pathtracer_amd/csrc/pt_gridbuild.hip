@@ -27,7 +27,7 @@ __device__ __forceinline__ int clamp_cell(int v, int hi) {
 struct CellRange { int a[3], b[3]; };
 
 __device__ __forceinline__ CellRange range_of(const ptl::GridBuildJob& job, int i) {
-	const float4 p = job.geo[(size_t)i * 8];          // position | bounding radius
+	const float4 p = job.geo[(size_t)i * ptl::REC_STRIDE];          // position | bounding radius
 	const float4 box = job.bbox[i];
 	const float pos[3] = { p.x, p.y, p.z }, dim[3] = { box.x, box.y, box.z };
 	CellRange r;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kBlock) void pt_k_grid_count(ptl::GridBuildJob job)
 	const int i = blockIdx.x * kBlock + threadIdx.x;
 	if(i >= job.n) return;
 	const CellRange r = range_of(job, i);
-	const int tf = __float_as_int(job.geo[(size_t)i * 8 + ptl::REC_DIM].w);
+	const int tf = __float_as_int(job.geo[(size_t)i * ptl::REC_STRIDE + ptl::REC_DIM].w);
 	const int type = tf & 0xff, flags = tf >> 8;
 	const uint32_t kind = type == PT_GEOM_SPHERE ? ((flags & 2) ? 0u : 3u) : type == PT_GEOM_BOX ? ((flags & 1) ? 2u : 1u) : type == PT_GEOM_CYLINDER ? 4u : 5u;
 	job.obj_range[2 * (size_t)i] = (uint32_t)r.a[0] | ((uint32_t)r.a[1] << 10) | ((uint32_t)r.a[2] << 20) | ((kind & 3u) << 30);
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void pt_k_grid_order(ptl::GridBuildJob job,
 			if(at[a] > ((lo >> (10 * a)) & 1023u)) tag |= 1u << (3 + 2 * a);
 			if(at[a] < ((hi >> (10 * a)) & 1023u)) tag |= 1u << (4 + 2 * a);
 		}
-		const float4 p = job.geo[(size_t)id * 8];
+		const float4 p = job.geo[(size_t)id * ptl::REC_STRIDE];
 		uint32_t radius = __float_as_uint(p.w);
 		if(radius & 0xffffu) radius = (radius & 0xffff0000u) + 0x10000u;
 		job.cell_entries[k] = make_float4(p.x, p.y, p.z, __uint_as_float(tag | radius));

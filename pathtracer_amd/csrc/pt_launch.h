@@ -19,6 +19,12 @@ struct Vec { float x, y, z; };
 //   REC_SCALEINV dimScaleInverse.xyz | -         (an unrotated box keeps its corners pos - dim/2, pos + dim/2 in REC_ROTINV, REC_SCALEINV)
 //   REC_ROT rot (w,x,y,z)     REC_SCALE dimScale.xyz | roughness     REC_COLOR colorLinear.rgb | reflectionMod     REC_EMIT emitColorLinear.rgb | refractiveIndex
 enum { REC_POS = 0, REC_ROTINV = 1, REC_DIM = 2, REC_SCALEINV = 3, REC_ROT = 4, REC_SCALE = 5, REC_COLOR = 6, REC_EMIT = 7, REC_SLOTS = 8 };
+// float4 slots from one record to the next (a diagnostic build may spread the records to see what their cache lines cost)
+#ifndef PT_REC_STRIDE
+#define PT_REC_STRIDE 8
+#endif
+enum { REC_STRIDE = PT_REC_STRIDE };
+static_assert(REC_STRIDE >= REC_SLOTS, "a record has eight slots");
 
 struct GridDev { int cmin[3], cnt[3], cs[3]; float inv_cs[3]; };
 
