@@ -103,6 +103,10 @@ def workload(name):
     if m:                                   # the demo scene at any size, for scaling studies
         world, objs = scenes.default_scene()
         return world, objs, dict(width=int(m.group(1)), height=int(m.group(2)), spp=int(m.group(3)), bounces=int(m.group(4)), seed=12345)
+    m = re.fullmatch(r"dense100k-(\d+)x(\d+)-(\d+)spp-d(\d+)", name)
+    if m:                                   # the 100 000-entity scene at any size (short items as at full size need >= 128 spp)
+        world, objs = scenes.dense_scene(n=100000, seed=4)
+        return world, objs, dict(width=int(m.group(1)), height=int(m.group(2)), spp=int(m.group(3)), bounces=int(m.group(4)), seed=12345, grid_hint=64)
     raise SystemExit(f"unknown workload {name}")
 
 

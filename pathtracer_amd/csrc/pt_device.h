@@ -472,8 +472,9 @@ PT_DEV float hit_round(bool cone, V3 p, V3 d, V3& pos, V3& nrm) {
 // takes the ray as it is, a unit-space one the transformed ray and the canonical shape (a centre of zero leaves every
 // difference and sum as it is: x - 0 and 0 + x are x, 0 - x is the box's lower corner as hit_box computes it).  Every lane
 // runs exactly the operation sequence of its intersect_kind variant.
+// p1 and p4 are the record's other two early slots, fetched by the caller together with p0 and p3.
 constexpr int KIND_MIXED = KIND_COUNT;
-PT_DEV float intersect_mixed(int kind, const GeoRef& g, v4f p0, v4f p3, V3 rp, V3 rd, V3& pos, V3& nrm) {
+PT_DEV float intersect_mixed(int kind, const GeoRef& g, v4f p0, v4f p1, v4f p3, v4f p4, V3 rp, V3 rd, V3& pos, V3& nrm) {
 	const V3 opos = v3(p0.x, p0.y, p0.z);
 	const V3 dim = v3(p3.x, p3.y, p3.z);
 	const bool isbox = kind == KIND_BOX_ROTATED;
@@ -481,14 +482,12 @@ PT_DEV float intersect_mixed(int kind, const GeoRef& g, v4f p0, v4f p3, V3 rp, V
 	const bool turned = isbox || (unit && ((__float_as_int(p3.w) >> 8) & FLAG_ROTATED));
 	V3 a = rp, ld = rd, sinv = v3(1, 1, 1);
 	if(unit) {
-		const v4f si = g.plane(G_SCALEINV);
-		sinv = v3(si.x, si.y, si.z);
+		sinv = v3(p4.x, p4.y, p4.z);
 		a = rp - opos;
 		V3 b = isbox ? a + rd : rd;
 		if(turned) {
-			const v4f ri = g.plane(G_ROTINV);
-			a = rotate(ri, a);
-			b = rotate(ri, b);
+			a = rotate(p1, a);
+			b = rotate(p1, b);
 		}
 		V3 din;
 		if(isbox) din = b - a;
@@ -503,9 +502,8 @@ PT_DEV float intersect_mixed(int kind, const GeoRef& g, v4f p0, v4f p3, V3 rp, V
 			bmin = v3(0, 0, 0) - half;
 			bmax = v3(0, 0, 0) + half;
 		} else {
-			const v4f lo = g.plane(G_BOX_LO), hi = g.plane(G_BOX_HI);
-			bmin = v3(lo.x, lo.y, lo.z);
-			bmax = v3(hi.x, hi.y, hi.z);
+			bmin = v3(p1.x, p1.y, p1.z);           // G_BOX_LO, G_BOX_HI
+			bmax = v3(p4.x, p4.y, p4.z);
 		}
 		distance = hit_slabs(a, ld, bmin, bmax, pos, nrm);
 	} else if(kind == KIND_SPHERE || kind == KIND_ELLIPSOID) {
@@ -747,7 +745,7 @@ PT_DEV int cast(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface& surf
 #define PT_COOP_CELLS 7
 #endif
 #ifndef PT_COOP_MIN_WALKING
-#define PT_COOP_MIN_WALKING 48
+#define PT_COOP_MIN_WALKING 32
 #endif
 constexpr int COOP_CELLS = PT_COOP_CELLS;               // cells a lane records per segment
 #ifndef PT_COOP_POOL
@@ -901,9 +899,12 @@ PT_MARK("chunk_fetched");
 	if(i < end) {
 		GeoRef g = { sc.geo, sc.n, id };
 		v4f p0 = g.plane(G_POS), p3 = g.plane(G_DIM);
-		lo = sc.obj_range[2 * id]; hi = sc.obj_range[2 * id + 1];     // wanted after a hit only; asked for now, with the record
+		// a chunk of mixed kinds asks for the whole first half of the record at once (G_ROTINV and G_SCALEINV, or an upright
+		// box's corners, in p1 and p4): one memory round trip instead of two for every unit-space candidate
+		v4f p1 = p0, p4 = p0;
+		if(KIND == KIND_MIXED) { p1 = g.plane(G_ROTINV); p4 = g.plane(G_SCALEINV); }
 		PT_TOCK_LANDED(sh, 9, tc);
-		distance = KIND == KIND_MIXED ? intersect_mixed(mixed_kind, g, p0, p3, rp, rd, pos, nrm) : intersect_kind<KIND>(g, p0, p3, rp, rd, pos, nrm);
+		distance = KIND == KIND_MIXED ? intersect_mixed(mixed_kind, g, p0, p1, p3, p4, rp, rd, pos, nrm) : intersect_kind<KIND>(g, p0, p3, rp, rd, pos, nrm);
 	}
 	PT_TOCK(sh, 3, tc);
 PT_MARK("chunk_intersected");
@@ -917,6 +918,7 @@ PT_MARK("chunk_intersected");
 	int q[3] = { 0, 0, 0 };
 	uint32_t on_bound = 0;
 	if(hit) {
+		lo = sc.obj_range[2 * id]; hi = sc.obj_range[2 * id + 1];         // the entity's cell range: fetched for hits only (two in five candidates)
 		const float pc[3] = { pos.x, pos.y, pos.z };
 		bool listed = true;
 		int rel[3];

@@ -326,7 +326,7 @@ def test_group_render_gathers_on_the_device(gpu, parts):
         assert sum(group.part_stats(k).paths for k in range(parts)) == gpu.stats().paths
     # abort: a long frame, stopped early
     world, objs = scenes.glass_scene(seed=3, per_type=16)
-    st = settings_for("glass", 1280, 720, 256, 32)
+    st = settings_for("glass", 1280, 720, 1024, 32)         # a quarter of a second of tracing
     whole = gpu.render(world, objs, st)
     out = np.full((720, 1280, 3), -3.0, np.float32)
     group.start(world, objs, st, out=out)
@@ -717,7 +717,7 @@ def test_abort_leaves_unfinished_pixels_alone_and_snapshots_grow(gpu):
     every other pixel keeps the caller's sentinel, and the progress record counts them."""
     world, objs = scenes.glass_scene(seed=3, per_type=16)
     W, H = 1920, 1080
-    st = settings_for("glass", W, H, 256, 32)             # a frame of a few hundred milliseconds
+    st = settings_for("glass", W, H, 512, 32)             # a frame of a few hundred milliseconds
     full = gpu.render(world, objs, st)
     sentinel = np.float32(-7.0)
     # a fresh context: its buffers have never held an image
