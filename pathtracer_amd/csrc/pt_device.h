@@ -1204,6 +1204,7 @@ PT_MARK("trip_ranked");
 			uint32_t who[COOP_ITEMS], id[COOP_ITEMS];
 			v4f e[COOP_ITEMS];
 			bool live[COOP_ITEMS];
+			V3 rop[COOP_ITEMS], rod[COOP_ITEMS];
 			#pragma unroll
 			for(int u = 0; u < COOP_ITEMS; u++) {
 				live[u] = item[u] < total;
@@ -1211,6 +1212,7 @@ PT_MARK("trip_ranked");
 				const uint32_t k = live[u] ? sh.desc_k0[d[u]] + (item[u] - (who[u] >> 12)) : 0u;
 				e[u] = sc.entries[k];
 				id[u] = sc.cell_items[k];
+				get6(sh.ray[who[u] & 63u], rop[u], rod[u]);       // the owner's ray: read while the entry travels
 			}
 			PT_TOCK_ISSUED(sh, 11, t0);
 			PT_TOCK_LANDED(sh, 8, t0);
@@ -1225,8 +1227,7 @@ PT_MARK("trip_loaded");
 					const bool dup = ((tag >> 3) >> ((who[u] >> 9) & 7u)) & 1u;        // face 7 (no previous cell) reads a zero bit
 					if(dup) PT_STAT(6, 1);
 					if(!dup) {
-						V3 op, od;
-						get6(sh.ray[owner], op, od);
+						const V3 op = rop[u], od = rod[u];
 						v4f ball = e[u];
 						ball.w = __uint_as_float(tag & 0xffff0000u);
 						if(!sphere_rejects(op, od, ball)) {
