@@ -474,7 +474,7 @@ PT_DEV float hit_round(bool cone, V3 p, V3 d, V3& pos, V3& nrm) {
 // runs exactly the operation sequence of its intersect_kind variant.
 // p1 and p4 are the record's other two early slots, fetched by the caller together with p0 and p3.
 constexpr int KIND_MIXED = KIND_COUNT;
-PT_DEV float intersect_mixed(int kind, const GeoRef& g, v4f p0, v4f p1, v4f p3, v4f p4, V3 rp, V3 rd, V3& pos, V3& nrm) {
+PT_DEV float intersect_mixed(int kind, const GeoRef& g, v4f p0, v4f p1, v4f p3, v4f p4, V3 rp, V3 rd, V3& pos, V3& nrm, cu32 range_words, uint32_t& range_lo, uint32_t& range_hi) {
 	const V3 opos = v3(p0.x, p0.y, p0.z);
 	const V3 dim = v3(p3.x, p3.y, p3.z);
 	const bool isbox = kind == KIND_BOX_ROTATED;
@@ -512,6 +512,9 @@ PT_DEV float intersect_mixed(int kind, const GeoRef& g, v4f p0, v4f p1, v4f p3, 
 	} else {
 		distance = hit_round(kind == KIND_CONE, a, ld, pos, nrm);
 	}
+	// anything but a miss: the entity's cell range (for the caller's cell search) is asked for together with the record's late
+	// slots (a unit-space distance of zero can still become a positive one in world space)
+	if(distance != -1) { range_lo = range_words[2 * g.i]; range_hi = range_words[2 * g.i + 1]; }
 	if(unit && distance != -1) {
 		if(!isbox) {
 			const v4f sc4 = g.plane(G_SCALE);
@@ -904,7 +907,7 @@ PT_MARK("chunk_fetched");
 		v4f p1 = p0, p4 = p0;
 		if(KIND == KIND_MIXED) { p1 = g.plane(G_ROTINV); p4 = g.plane(G_SCALEINV); }
 		PT_TOCK_LANDED(sh, 9, tc);
-		distance = KIND == KIND_MIXED ? intersect_mixed(mixed_kind, g, p0, p1, p3, p4, rp, rd, pos, nrm) : intersect_kind<KIND>(g, p0, p3, rp, rd, pos, nrm);
+		distance = KIND == KIND_MIXED ? intersect_mixed(mixed_kind, g, p0, p1, p3, p4, rp, rd, pos, nrm, sc.obj_range, lo, hi) : intersect_kind<KIND>(g, p0, p3, rp, rd, pos, nrm);
 	}
 	PT_TOCK(sh, 3, tc);
 PT_MARK("chunk_intersected");
@@ -918,7 +921,8 @@ PT_MARK("chunk_intersected");
 	int q[3] = { 0, 0, 0 };
 	uint32_t on_bound = 0;
 	if(hit) {
-		lo = sc.obj_range[2 * id]; hi = sc.obj_range[2 * id + 1];         // the entity's cell range: fetched for hits only (two in five candidates)
+		// the entity's cell range: fetched for hits only (two in five candidates); a chunk of mixed kinds has asked for it already
+		if(KIND != KIND_MIXED) { lo = sc.obj_range[2 * id]; hi = sc.obj_range[2 * id + 1]; }
 		const float pc[3] = { pos.x, pos.y, pos.z };
 		bool listed = true;
 		int rel[3];
