@@ -393,7 +393,7 @@ def test_headless_harness(gpu, tmp_path):
 
 
 def test_determinism_and_range_at_full_size(gpu):
-    """BASELINE size (1080p, 64 spp, depth 8): two runs are bitwise equal, the image is finite and in
+    """The headline size (1080p, 64 spp, depth 8): two runs are bitwise equal, the image is finite and in
     [0,1], primary ids equal the oracle's, sky rows are exactly the background colour."""
     world, objs = scenes.default_scene()
     st = default_settings(1920, 1080, 64, 8, seed=12345)
