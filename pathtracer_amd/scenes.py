@@ -177,3 +177,20 @@ def plain_scene(seed=5, n=8):
         else:
             objs.append(make_object(pos, (rng.uniform(1.5, 5), rng.uniform(1.5, 5), rng.uniform(1.5, 5)), PT_GEOM_BOX, color=col, refl=refl, emit=emit))
     return world, objs
+
+
+def aligned_boxes_scene():
+    """Sixteen upright boxes on a lattice whose faces lie on multiples of 6 in x and y and on integers in z.  With
+    grid_hint 14 the grid's cells are 6 x 6 x 1 (code/raycast.cpp:595-617: cell size = extent / hint, truncated), so every
+    face lies on cell bounds: hit points sit exactly on a cell's lower or upper bound, or an ulp beside it, which is where
+    the rule "the hit counts for the first visited cell whose closed box holds it" (code/raycast.cpp:957-983) is decided."""
+    world = make_world(cam_pos=(3, -70, 22), cam_rot=(0, -0.3, 0), fov=80.0)
+    objs = []
+    for i in range(4):
+        for j in range(4):
+            x0, y0 = 24 * i - 42, 24 * j - 42
+            top = 4 * (1 + (i + 2 * j) % 3)
+            shade = 0.35 + 0.04 * (i + 4 * j)
+            refl = 1.0 if (i + j) % 5 == 0 else 0.0
+            objs.append(make_object((x0 + 6, y0 + 6, top / 2), (12, 12, top), PT_GEOM_BOX, color=(shade, 0.6, 1 - shade), refl=refl))
+    return world, objs

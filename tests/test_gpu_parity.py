@@ -51,8 +51,10 @@ CASES = {
     # (the lean kernel variant, like "default")
     "small_mixed": (lambda: scenes.mixed_scene(seed=11, n=8), 10, 10),
     "plain9": (lambda: scenes.plain_scene(seed=5, n=8), 10, 10),
+    # upright boxes whose faces all lie on cell bounds (cells of 6 x 6 x 1): hit points on a cell's bound or an ulp beside it
+    "aligned_boxes": (lambda: scenes.aligned_boxes_scene(), 14, 10),
 }
-ROUGH_FREE = {"default", "default_grid", "plain9"}
+ROUGH_FREE = {"default", "default_grid", "plain9", "aligned_boxes"}
 
 
 def settings_for(name, w, h, spp, bounces, seed=4242, **kw):
@@ -67,7 +69,19 @@ def test_cast_rays_bit_exact(gpu, name):
     gpu.prepare(world, objs, st)
     sc = OracleScene(world, objs, st)
     n = 40000
-    o, d = scene_rays(n, 77, objs, spread=30.0 if name != "dense2k" else 60.0)
+    o, d = scene_rays(n, 77, objs, spread={"dense2k": 60.0, "aligned_boxes": 60.0}.get(name, 30.0))
+    if name == "aligned_boxes":
+        # a quarter of the rays run along an axis onto the faces: their hit points lie exactly on cell bounds
+        rng = np.random.default_rng(5)
+        k = n // 4
+        axis = rng.integers(0, 3, k)
+        sign = rng.choice(np.array([-1.0, 1.0], np.float32), k)
+        oo = rng.uniform(-45, 45, (k, 3)).astype(np.float32)
+        oo[:, 2] = rng.uniform(0.25, 11.75, k).astype(np.float32)
+        dd = np.zeros((k, 3), np.float32)
+        dd[np.arange(k), axis] = sign
+        oo[np.arange(k), axis] = -sign * np.float32(70.0)
+        o[:k], d[:k] = oo, dd
     ids, pos, nrm = gpu.cast_rays(o, d)
     rid, rpos, rnrm = np.zeros(n, np.int32), np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
     use_grid = 0 if len(objs) < st.brute_force_below else 1
@@ -79,6 +93,10 @@ def test_cast_rays_bit_exact(gpu, name):
     hit = (rid != 0) & ~bad
     assert (bits(pos[hit]) == bits(rpos[hit])).all(), "hit positions differ"
     assert (bits(nrm[hit]) == bits(rnrm[hit])).all(), "hit normals differ"
+    if name == "aligned_boxes":
+        h = rpos[hit].astype(np.float64)
+        on_bound = (np.mod(h[:, 0], 6) == 0) | (np.mod(h[:, 1], 6) == 0) | (np.mod(h[:, 2], 1) == 0)
+        assert on_bound.sum() > 5000, "the ray set must put many hit points exactly on cell bounds"
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -99,7 +117,8 @@ def test_primary_ids_and_cell_hashes(gpu, name):
 @pytest.mark.parametrize("name,w,h,spp,bounces", [("default", 320, 180, 16, 8), ("default_grid", 160, 90, 16, 8),
                                                    ("mixed40", 160, 90, 16, 8), ("glass", 160, 90, 16, 32),
                                                    ("crowded", 128, 72, 4, 8), ("dense2k", 128, 72, 4, 8),
-                                                   ("small_mixed", 160, 90, 16, 16), ("plain9", 160, 90, 16, 8)])
+                                                   ("small_mixed", 160, 90, 16, 16), ("plain9", 160, 90, 16, 8),
+                                                   ("aligned_boxes", 160, 90, 16, 8)])
 def test_image_parity(gpu, name, w, h, spp, bounces):
     world, objs = CASES[name][0]()
     st = settings_for(name, w, h, spp, bounces)
