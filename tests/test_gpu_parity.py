@@ -99,6 +99,26 @@ def test_cast_rays_bit_exact(gpu, name):
         assert on_bound.sum() > 5000, "the ray set must put many hit points exactly on cell bounds"
 
 
+@pytest.mark.parametrize("seed", [21, 22, 23, 24, 25, 26])
+def test_cast_rays_bit_exact_on_more_scenes(gpu, seed):
+    """The same comparison on six more scenes of every kind (rotated and upright, crowded enough that a wavefront's chunk
+    of candidates holds all kinds at once): ids, hit positions and normals of 30 000 rays each, bit for bit."""
+    world, objs = scenes.mixed_scene(seed=seed, n=40 + 20 * (seed % 3), spread=10.0 + 2 * (seed % 4))
+    st = default_settings(64, 36, 4, 4, seed=4242, grid_hint=8 + seed % 5, brute_force_below=10)
+    gpu.prepare(world, objs, st)
+    sc = OracleScene(world, objs, st)
+    n = 30000
+    o, d = scene_rays(n, seed, objs, spread=25.0)
+    ids, pos, nrm = gpu.cast_rays(o, d)
+    rid, rpos, rnrm = np.zeros(n, np.int32), np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    sc.lib.pto_cast(sc.h, n, P(o), P(d), 1, rid.ctypes.data_as(IP), P(rpos), P(rnrm))
+    sc.close()
+    assert (rid != 0).mean() > 0.25
+    assert (ids == rid).all(), f"{(ids != rid).sum()} of {n} entity ids differ"
+    hit = rid != 0
+    assert (bits(pos[hit]) == bits(rpos[hit])).all() and (bits(nrm[hit]) == bits(rnrm[hit])).all()
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_primary_ids_and_cell_hashes(gpu, name):
     world, objs = CASES[name][0]()
