@@ -315,9 +315,7 @@ int prepare(pt_ctx* c) {
 		std::vector<uint32_t> ranges;
 		coop = pt::object_ranges(rec.data(), n, gd, &ranges);
 		if((rc = upload(c, c->obj_range, ranges.data(), ranges.size() * 4))) return rc;
-		// What the cooperative cast's collection step needs of a list entry, in 16 bytes: the bounding
-		// sphere (radius rounded up to its upper 16 bits), in which of the six neighbour cells the
-		// entity is listed as well (bits 3..8: -x +x -y +y -z +z), and its intersection kind (bits 0..2).
+		// What the cooperative cast's collection step needs of a list entry, in 16 bytes (ptl::pack_entry)
 		std::vector<float> entries(coop ? (cell_items.size() + 1) * 4 : 4, 0.0f);
 		const int64_t cells = coop ? gd.cells() : 0;
 		for(int64_t cell = 0; cell < cells; cell++) {
@@ -332,13 +330,9 @@ int prepare(pt_ctx* c) {
 					if(at[a] > ((lo >> (10 * a)) & 1023u)) tag |= 1u << (3 + 2 * a);
 					if(at[a] < ((hi >> (10 * a)) & 1023u)) tag |= 1u << (4 + 2 * a);
 				}
-				uint32_t radius;
-				memcpy(&radius, r + PT_F_BRADIUS, 4);
-				if(radius & 0xffffu) radius = (radius & 0xffff0000u) + 0x10000u;
-				tag |= radius;
-				float* e = entries.data() + (size_t)k * 4;
-				e[0] = r[PT_F_POS]; e[1] = r[PT_F_POS + 1]; e[2] = r[PT_F_POS + 2];
-				memcpy(e + 3, &tag, 4);
+				uint32_t w[4];
+				ptl::pack_entry(r[PT_F_POS], r[PT_F_POS + 1], r[PT_F_POS + 2], r[PT_F_BRADIUS], tag, id, w);
+				memcpy(entries.data() + (size_t)k * 4, w, 16);
 			}
 		}
 		if((rc = upload(c, c->cell_entries, entries.data(), entries.size() * 4))) return rc;

@@ -35,7 +35,7 @@ struct Scene {
 	cf4 geo, dirs;
 	cf2 disc, samples;
 	cu32 cell_start, cell_items, obj_range;
-	cf4 entries;                 // per cell-list entry: bounding-sphere centre | radius (upper 16 bits, rounded up), listed-in-neighbour mask << 3, kind
+	cf4 entries;                 // per cell-list entry: bounding sphere, listed-in-neighbour mask, kind, id (ptl::pack_entry)
 	ci32 offsets;
 	int n, brute;
 	Grid grid;
@@ -1205,7 +1205,7 @@ PT_MARK("trip_begin");
 				d[u] = (past && item[u] < total) ? ndesc - 1u : (uint32_t)sh.rank0[pos >> 5] + (uint32_t)__popc(heads) - 1u;
 			}
 PT_MARK("trip_ranked");
-			uint32_t who[COOP_ITEMS], id[COOP_ITEMS];
+			uint32_t who[COOP_ITEMS];
 			v4f e[COOP_ITEMS];
 			bool live[COOP_ITEMS];
 			V3 rop[COOP_ITEMS], rod[COOP_ITEMS];
@@ -1215,7 +1215,6 @@ PT_MARK("trip_ranked");
 				who[u] = sh.desc_at[d[u]];
 				const uint32_t k = live[u] ? sh.desc_k0[d[u]] + (item[u] - (who[u] >> 12)) : 0u;
 				e[u] = sc.entries[k];
-				id[u] = sc.cell_items[k];
 				get6(sh.ray[who[u] & 63u], rop[u], rod[u]);       // the owner's ray: read while the entry travels
 			}
 			PT_TOCK_ISSUED(sh, 11, t0);
@@ -1228,17 +1227,18 @@ PT_MARK("trip_loaded");
 					const uint32_t tag = __float_as_uint(e[u].w);
 					PT_STAT(5, 1);
 					// an entity that is also listed in the cell the ray came from was collected there
-					const bool dup = ((tag >> 3) >> ((who[u] >> 9) & 7u)) & 1u;        // face 7 (no previous cell) reads a zero bit
+					const bool dup = (((tag >> 3) & 63u) >> ((who[u] >> 9) & 7u)) & 1u;        // face 7 (no previous cell) reads a zero bit
 					if(dup) PT_STAT(6, 1);
 					if(!dup) {
 						const V3 op = rop[u], od = rod[u];
-						v4f ball = e[u];
+						v4f ball = e[u];                 // the id's bits move the centre by less than the radius was enlarged by
 						ball.w = __uint_as_float(tag & 0xffff0000u);
 						if(!sphere_rejects(op, od, ball)) {
 							uint32_t kind = tag & 7u;
+							const uint32_t id = ptl::entry_id(__float_as_uint(e[u].x), __float_as_uint(e[u].y), __float_as_uint(e[u].z), tag);
 							uint32_t slot = atomicAdd(&sh.count[KIND_COUNT], 1u);
 							atomicAdd(&sh.count[kind], 1u);
-							sh.pool[slot] = ((uint32_t)owner << 26) | (kind << 23) | id[u];
+							sh.pool[slot] = ((uint32_t)owner << 26) | (kind << 23) | id;
 						} else PT_STAT(7, 1);
 					}
 				}

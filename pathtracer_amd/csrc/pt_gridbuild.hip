@@ -131,8 +131,7 @@ __global__ __launch_bounds__(kBlock) void pt_k_grid_fill(ptl::GridBuildJob job) 
 	}
 }
 
-// Ascending ids inside every cell, then the cooperative cast's list entries: bounding-sphere centre |
-// radius rounded up to its upper 16 bits, listed-in-neighbour bits 3..8 (-x +x -y +y -z +z), kind bits 0..2.
+// Ascending ids inside every cell, then the cooperative cast's list entries (ptl::pack_entry).
 __global__ __launch_bounds__(kBlock) void pt_k_grid_order(ptl::GridBuildJob job, size_t cells) {
 	const size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
 	if(c >= cells) return;
@@ -156,9 +155,9 @@ __global__ __launch_bounds__(kBlock) void pt_k_grid_order(ptl::GridBuildJob job,
 			if(at[a] < ((hi >> (10 * a)) & 1023u)) tag |= 1u << (4 + 2 * a);
 		}
 		const float4 p = job.geo[(size_t)id * ptl::REC_STRIDE];
-		uint32_t radius = __float_as_uint(p.w);
-		if(radius & 0xffffu) radius = (radius & 0xffff0000u) + 0x10000u;
-		job.cell_entries[k] = make_float4(p.x, p.y, p.z, __uint_as_float(tag | radius));
+		uint32_t w[4];
+		ptl::pack_entry(p.x, p.y, p.z, p.w, tag, id, w);
+		job.cell_entries[k] = make_float4(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]));
 	}
 }
 

@@ -28,11 +28,40 @@ static_assert(REC_STRIDE >= REC_SLOTS, "a record has eight slots");
 
 struct GridDev { int cmin[3], cnt[3], cs[3]; float inv_cs[3]; };
 
+// A list entry of the cooperative cast, 16 bytes: the entity's bounding sphere, its intersection kind (tag bits 0..2), in which
+// of the six neighbour cells it is listed as well (tag bits 3..8: -x +x -y +y -z +z) - and its id, so that collecting
+// candidates reads one array, not two.  The id (23 bits) rides where the sphere can spare bits: bits 0..6 in tag bits 9..15,
+// bits 7..12 in the low six mantissa bits of the centre's x, 13..17 and 18..22 in the low five of y and z.  The radius (tag
+// bits 16..31, rounded up) grows by what those bits can move the centre, so the sphere still encloses the entity's own.
+constexpr uint32_t ENTRY_ID_LIMIT = 1u << 23;
+__host__ __device__ inline float entry_ulp(float v) {          // spacing of the floats at |v| (v finite)
+	union { float f; uint32_t u; } w;
+	w.f = v;
+	uint32_t e = (w.u >> 23) & 255u;
+	if(e < 24u) e = 24u;                                        // a tiny or zero coordinate: an upper bound is enough
+	w.u = (e - 23u) << 23;
+	return w.f;
+}
+__host__ __device__ inline void pack_entry(float x, float y, float z, float radius, uint32_t kind_and_neighbours, uint32_t id, uint32_t out[4]) {
+	union { float f; uint32_t u; } w;
+	const float pad = (64.0f * entry_ulp(x) + 32.0f * entry_ulp(y)) + 32.0f * entry_ulp(z);
+	w.f = (radius + pad) * 1.000001f;
+	uint32_t r = w.u;
+	if(r & 0xffffu) r = (r & 0xffff0000u) + 0x10000u;
+	w.f = x; out[0] = (w.u & ~63u) | ((id >> 7) & 63u);
+	w.f = y; out[1] = (w.u & ~31u) | ((id >> 13) & 31u);
+	w.f = z; out[2] = (w.u & ~31u) | ((id >> 18) & 31u);
+	out[3] = r | ((id & 127u) << 9) | (kind_and_neighbours & 511u);
+}
+__host__ __device__ inline uint32_t entry_id(uint32_t x, uint32_t y, uint32_t z, uint32_t tag) {
+	return ((tag >> 9) & 127u) | ((x & 63u) << 7) | ((y & 31u) << 13) | ((z & 31u) << 18);
+}
+
 struct SceneDev {
 	const float4* geo;
 	const uint32_t* cell_start;
 	const uint32_t* cell_items;
-	const float4* cell_entries; // cooperative cast: one float4 per cell_items entry (bounding sphere, neighbour mask, kind)
+	const float4* cell_entries; // cooperative cast: one float4 per cell_items entry (pack_entry)
 	const uint32_t* obj_range;  // per entity: inclusive cell range, 10 bits per axis, and its intersection kind (2 words)
 	const float4* dirs;
 	const float2* disc;
