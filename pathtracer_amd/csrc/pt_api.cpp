@@ -170,6 +170,37 @@ int upload(pt_ctx* c, DevBuf& b, const void* src, size_t bytes) {
 	return PT_OK;
 }
 
+// The grid as the device passes see it, with the memory order of its cells chosen (ptl::grid_layout).
+ptl::GridDev grid_dev(const pt::GridDesc& gd) {
+	ptl::GridDev g{};
+	for(int k = 0; k < 3; k++) { g.cmin[k] = gd.coord_min[k]; g.cnt[k] = gd.cell_count[k]; g.cs[k] = gd.cell_size[k]; g.inv_cs[k] = 1.0f / (float)gd.cell_size[k]; }
+	ptl::grid_layout(g);
+	return g;
+}
+
+// Per-cell lists between the reference's cell order (x fastest: what pt::build_grid writes and pt_debug_grid reports) and the
+// device's (ptl::grid_layout).  to_device: `start`, `items` come in the reference's order and leave in the device's; else the reverse.
+void reorder_lists(const ptl::GridDev& g, bool to_device, std::vector<uint32_t>* start, std::vector<uint32_t>* items) {
+	if(ptl::grid_layout_is_reference(g)) return;
+	const size_t cells = (size_t)g.cnt[0] * (size_t)g.cnt[1] * (size_t)g.cnt[2];
+	std::vector<uint32_t> new_start(cells + 1, 0), new_items(items->size());
+	// the same cell's index in the other order
+	auto other = [&](size_t cell, bool cell_is_device) {
+		uint32_t at[3];
+		if(cell_is_device) { ptl::grid_cell_coords(g, cell, at); return ((size_t)at[2] * (size_t)g.cnt[1] + (size_t)at[1]) * (size_t)g.cnt[0] + (size_t)at[0]; }
+		at[0] = (uint32_t)(cell % (size_t)g.cnt[0]); at[1] = (uint32_t)((cell / (size_t)g.cnt[0]) % (size_t)g.cnt[1]); at[2] = (uint32_t)(cell / ((size_t)g.cnt[0] * (size_t)g.cnt[1]));
+		return ptl::grid_cell(g, (int)at[0], (int)at[1], (int)at[2]);
+	};
+	for(size_t o = 0; o < cells; o++) {
+		const size_t in = other(o, to_device);
+		const uint32_t a = (*start)[in], b = (*start)[in + 1];
+		new_start[o + 1] = new_start[o] + (b - a);
+		for(uint32_t k = a; k < b; k++) new_items[new_start[o] + (k - a)] = (*items)[k];
+	}
+	start->swap(new_start);
+	items->swap(new_items);
+}
+
 // Per-cell lists, entity cell ranges and the cooperative cast's list entries built on the device
 // (pt_gridbuild.hip) from the uploaded entity records.  *done is false when a cell lists more than
 // kLongestDeviceList entities: the ordering pass sorts a list with one thread, so the host builds then.
@@ -190,7 +221,7 @@ int grid_build_device(pt_ctx* c, const std::vector<float>& rec, int n, const pt:
 	job.geo = c->geo.as<float4>();
 	job.bbox = c->bbox.as<float4>();
 	job.n = n;
-	for(int k = 0; k < 3; k++) { job.grid.cmin[k] = gd.coord_min[k]; job.grid.cnt[k] = gd.cell_count[k]; job.grid.cs[k] = gd.cell_size[k]; job.grid.inv_cs[k] = 1.0f / (float)gd.cell_size[k]; }
+	job.grid = grid_dev(gd);
 	job.obj_range = c->obj_range.as<uint32_t>();
 	job.cell_start = c->cell_start.as<uint32_t>();
 	job.cursor = c->grid_cursor.as<uint32_t>();
@@ -309,6 +340,8 @@ int prepare(pt_ctx* c) {
 	}
 	if(!grid_on_device) {
 		if(have_grid) pt::build_grid(rec.data(), n, s.grid_hint, &gd, &cell_start, &cell_items);
+		const ptl::GridDev layout = grid_dev(gd);
+		reorder_lists(layout, true, &cell_start, &cell_items);
 		item_total = cell_items.size();
 		if((rc = upload(c, c->cell_start, cell_start.data(), cell_start.size() * 4))) return rc;
 		if((rc = upload(c, c->cell_items, cell_items.data(), cell_items.size() * 4))) return rc;
@@ -319,8 +352,8 @@ int prepare(pt_ctx* c) {
 		std::vector<float> entries(coop ? (cell_items.size() + 1) * 4 : 4, 0.0f);
 		const int64_t cells = coop ? gd.cells() : 0;
 		for(int64_t cell = 0; cell < cells; cell++) {
-			const uint32_t at[3] = { (uint32_t)(cell % gd.cell_count[0]), (uint32_t)((cell / gd.cell_count[0]) % gd.cell_count[1]),
-			                         (uint32_t)(cell / ((int64_t)gd.cell_count[0] * gd.cell_count[1])) };
+			uint32_t at[3];
+			ptl::grid_cell_coords(layout, (size_t)cell, at);
 			for(uint32_t k = cell_start[(size_t)cell]; k < cell_start[(size_t)cell + 1]; k++) {
 				const uint32_t id = cell_items[k];
 				const float* r = rec.data() + (size_t)id * PT_F_STRIDE;
@@ -394,7 +427,7 @@ int prepare(pt_ctx* c) {
 	j.scene.offsets = c->offsets.as<int32_t>();
 	j.scene.n = n;
 	j.scene.brute = n < s.brute_force_below ? 1 : 0;
-	for(int k = 0; k < 3; k++) { j.scene.grid.cmin[k] = gd.coord_min[k]; j.scene.grid.cnt[k] = gd.cell_count[k]; j.scene.grid.cs[k] = gd.cell_size[k]; j.scene.grid.inv_cs[k] = 1.0f / (float)gd.cell_size[k]; }
+	j.scene.grid = grid_dev(gd);
 
 	// per-job constants of the tile job (code/raycast.cpp:1010-1021), evaluated once on the host
 	ptl::FrameDev f{};
@@ -1506,13 +1539,16 @@ int pt_debug_grid(pt_ctx* c, uint32_t* cell_start, int cell_capacity, uint32_t* 
 	if(cell_total) *cell_total = (int)cells;
 	if(item_total) *item_total = (int)items;
 	if(built_on_device) *built_on_device = c->grid_built_on_device ? 1 : 0;
-	if(cell_start) {
-		if((size_t)cell_capacity < cells + 1) return fail(c, PT_ERR_LIMIT, "cell_start needs %zu words", cells + 1);
-		PT_HIP(c, hipMemcpy(cell_start, c->cell_start.p, (cells + 1) * 4, hipMemcpyDeviceToHost));
-	}
-	if(cell_items && items > 0) {
-		if((size_t)item_capacity < items) return fail(c, PT_ERR_LIMIT, "cell_items needs %zu words", items);
-		PT_HIP(c, hipMemcpy(cell_items, c->cell_items.p, items * 4, hipMemcpyDeviceToHost));
+	if(cell_start && (size_t)cell_capacity < cells + 1) return fail(c, PT_ERR_LIMIT, "cell_start needs %zu words", cells + 1);
+	if(cell_items && items > 0 && (size_t)item_capacity < items) return fail(c, PT_ERR_LIMIT, "cell_items needs %zu words", items);
+	if(cell_start || (cell_items && items > 0)) {
+		// the lists are reported in the reference's cell order, whatever order the device keeps them in
+		std::vector<uint32_t> start(cells + 1, 0), list(items, 0);
+		PT_HIP(c, hipMemcpy(start.data(), c->cell_start.p, (cells + 1) * 4, hipMemcpyDeviceToHost));
+		if(items > 0) PT_HIP(c, hipMemcpy(list.data(), c->cell_items.p, items * 4, hipMemcpyDeviceToHost));
+		reorder_lists(c->job.scene.grid, false, &start, &list);
+		if(cell_start) memcpy(cell_start, start.data(), (cells + 1) * 4);
+		if(cell_items && items > 0) memcpy(cell_items, list.data(), items * 4);
 	}
 	if(obj_range && c->stats.objects > 0) PT_HIP(c, hipMemcpy(obj_range, c->obj_range.p, (size_t)c->stats.objects * 8, hipMemcpyDeviceToHost));
 	return PT_OK;

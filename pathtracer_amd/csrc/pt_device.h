@@ -647,7 +647,6 @@ PT_DEV bool lite_next(const Grid& g, WalkLite& w) {
 	}
 	return true;
 }
-PT_DEV int lite_cell(const Grid& g, const WalkLite& w) { return w.cz * g.cnt[1] * g.cnt[0] + w.cy * g.cnt[0] + w.cx; }
 
 #define PT_HASH_INIT 1469598103934665603ULL
 PT_DEV uint64_t hash_cell(uint64_t h, int index) { return (h ^ (uint64_t)(uint32_t)(index + 1)) * 1099511628211ULL; }
@@ -701,8 +700,8 @@ PT_DEV int cast_grid(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface&
 	int id = 0;
 	float best = 3.402823466e+38f;
 	do {
-		int cell = w.cz * sc.grid.cnt[1] * sc.grid.cnt[0] + w.cy * sc.grid.cnt[0] + w.cx;
-		if(HASH) hash = hash_cell(hash, cell);
+		if(HASH) hash = hash_cell(hash, w.cz * sc.grid.cnt[1] * sc.grid.cnt[0] + w.cy * sc.grid.cnt[0] + w.cx);     // the reference's cell index
+		const int cell = w.cx * sc.grid.stride[0] + w.cy * sc.grid.stride[1] + w.cz * sc.grid.stride[2];           // where the cell sits here (ptl::grid_layout)
 		uint32_t k0 = sc.cell_start[cell], k1 = sc.cell_start[cell + 1];
 		for(uint32_t k = k0; k < k1; k++) {
 			int oi = (int)sc.cell_items[k];
@@ -1092,11 +1091,12 @@ PT_MARK("walk_begin");
 			// the face a step enters the next cell through: -x +x -y +y -z +z, 7 for the cell the segment starts in
 			const uint32_t fx = (uint32_t)sx >> 31, fy = 2u + ((uint32_t)sy >> 31), fz = 4u + ((uint32_t)sz >> 31);
 			const int nx = sc.grid.cnt[0], ny = sc.grid.cnt[1], nz = sc.grid.cnt[2];
+			const int s0 = sc.grid.stride[0], s1 = sc.grid.stride[1], s2 = sc.grid.stride[2];
 			uint32_t face = 7;
 			int pc[COOP_CELLS];
 			#pragma unroll
 			for(int j = 0; j < COOP_CELLS; j++) {
-				pc[j] = more ? (cz * ny + cy) * nx + cx : 0;
+				pc[j] = more ? cx * s0 + cy * s1 + cz * s2 : 0;
 				cc[j] = pack_cell(cx, cy, cz);
 				fc[j] = face;
 				m += more ? 1 : 0;

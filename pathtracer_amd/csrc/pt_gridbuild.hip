@@ -54,9 +54,8 @@ __global__ __launch_bounds__(kBlock) void pt_k_grid_count(ptl::GridBuildJob job)
 	const uint32_t kind = type == PT_GEOM_SPHERE ? ((flags & 2) ? 0u : 3u) : type == PT_GEOM_BOX ? ((flags & 1) ? 2u : 1u) : type == PT_GEOM_CYLINDER ? 4u : 5u;
 	job.obj_range[2 * (size_t)i] = (uint32_t)r.a[0] | ((uint32_t)r.a[1] << 10) | ((uint32_t)r.a[2] << 20) | ((kind & 3u) << 30);
 	job.obj_range[2 * (size_t)i + 1] = (uint32_t)r.b[0] | ((uint32_t)r.b[1] << 10) | ((uint32_t)r.b[2] << 20) | ((kind >> 2) << 30);
-	const size_t cx = (size_t)job.grid.cnt[0], cy = (size_t)job.grid.cnt[1];
 	for(int z = r.a[2]; z <= r.b[2]; z++) for(int y = r.a[1]; y <= r.b[1]; y++) for(int x = r.a[0]; x <= r.b[0]; x++)
-		atomicAdd(&job.cell_start[((size_t)z * cy + (size_t)y) * cx + (size_t)x + 1], 1u);
+		atomicAdd(&job.cell_start[ptl::grid_cell(job.grid, x, y, z) + 1], 1u);
 }
 
 // Inclusive scan of kPerBlock values per block, in place; the block's total goes to totals[block].
@@ -124,9 +123,8 @@ __global__ __launch_bounds__(kBlock) void pt_k_grid_fill(ptl::GridBuildJob job) 
 	const int i = blockIdx.x * kBlock + threadIdx.x;
 	if(i >= job.n) return;
 	const CellRange r = range_of(job, i);
-	const size_t cx = (size_t)job.grid.cnt[0], cy = (size_t)job.grid.cnt[1];
 	for(int z = r.a[2]; z <= r.b[2]; z++) for(int y = r.a[1]; y <= r.b[1]; y++) for(int x = r.a[0]; x <= r.b[0]; x++) {
-		const size_t c = ((size_t)z * cy + (size_t)y) * cx + (size_t)x;
+		const size_t c = ptl::grid_cell(job.grid, x, y, z);
 		job.cell_items[job.cell_start[c] + atomicAdd(&job.cursor[c], 1u)] = (uint32_t)i;
 	}
 }
@@ -144,8 +142,8 @@ __global__ __launch_bounds__(kBlock) void pt_k_grid_order(ptl::GridBuildJob job,
 		list[j] = id;
 	}
 	if(!job.cell_entries) return;
-	const uint32_t at[3] = { (uint32_t)(c % (size_t)job.grid.cnt[0]), (uint32_t)((c / (size_t)job.grid.cnt[0]) % (size_t)job.grid.cnt[1]),
-	                         (uint32_t)(c / ((size_t)job.grid.cnt[0] * (size_t)job.grid.cnt[1])) };
+	uint32_t at[3];
+	ptl::grid_cell_coords(job.grid, c, at);
 	for(uint32_t k = k0; k < k1; k++) {
 		const uint32_t id = list[k];
 		const uint32_t lo = job.obj_range[2 * (size_t)id], hi = job.obj_range[2 * (size_t)id + 1];
