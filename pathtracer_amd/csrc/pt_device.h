@@ -1091,12 +1091,15 @@ PT_MARK("walk_begin");
 			// the face a step enters the next cell through: -x +x -y +y -z +z, 7 for the cell the segment starts in
 			const uint32_t fx = (uint32_t)sx >> 31, fy = 2u + ((uint32_t)sy >> 31), fz = 4u + ((uint32_t)sz >> 31);
 			const int nx = sc.grid.cnt[0], ny = sc.grid.cnt[1], nz = sc.grid.cnt[2];
+			// the cell's index follows the steps: integer multiplies cost two ordinary instructions each
 			const int s0 = sc.grid.stride[0], s1 = sc.grid.stride[1], s2 = sc.grid.stride[2];
+			int at = cx * s0 + cy * s1 + cz * s2;
+			const int ix = sx > 0 ? s0 : sx < 0 ? -s0 : 0, iy = sy > 0 ? s1 : sy < 0 ? -s1 : 0, iz = sz > 0 ? s2 : sz < 0 ? -s2 : 0;
 			uint32_t face = 7;
 			int pc[COOP_CELLS];
 			#pragma unroll
 			for(int j = 0; j < COOP_CELLS; j++) {
-				pc[j] = more ? cx * s0 + cy * s1 + cz * s2 : 0;
+				pc[j] = more ? at : 0;
 				cc[j] = pack_cell(cx, cy, cz);
 				fc[j] = face;
 				m += more ? 1 : 0;
@@ -1105,6 +1108,7 @@ PT_MARK("walk_begin");
 				const bool az = !(ax || ay);
 				face = ax ? fx : ay ? fy : fz;
 				cx += ax ? sx : 0; cy += ay ? sy : 0; cz += az ? sz : 0;
+				at += ax ? ix : ay ? iy : iz;
 				const float ux = tx + st.dx, uy = ty + st.dy, uz = tz + st.dz;
 				tx = ax ? ux : tx; ty = ay ? uy : ty; tz = az ? uz : tz;
 				more = more && (uint32_t)cx < (uint32_t)nx && (uint32_t)cy < (uint32_t)ny && (uint32_t)cz < (uint32_t)nz;
