@@ -348,6 +348,14 @@ int pt_host_grid(const float* records, int n, int hint, int32_t* grid_ints /* 9 
                  uint32_t* cell_start, int cell_capacity, uint32_t* cell_items, int item_capacity,
                  int* cell_total, int* item_total);
 
+/* The two device-side conventions of the grid that have no counterpart in the reference, exposed for tests.
+ * pt_host_list_entry: the 16-byte list entry of the cooperative cast for an entity with bounding sphere (centre, radius),
+ * tag = intersection kind | listed-in-neighbour bits << 3 (9 bits) and index id (< 2^23); *id_back = the id read back out
+ * of the entry.  pt_host_cell_order: the strides (in cells) of x, y, z in the device's cell arrays for a grid of
+ * cell_count[3] cells of cell_size[3] units. */
+int pt_host_list_entry(const float centre[3], float radius, uint32_t tag, uint32_t id, uint32_t entry[4], uint32_t* id_back);
+int pt_host_cell_order(const int32_t cell_count[3], const int32_t cell_size[3], int32_t stride[3]);
+
 #ifdef __cplusplus
 }
 #endif

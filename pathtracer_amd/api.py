@@ -193,6 +193,8 @@ def load_core():
     lib.pt_host_grid.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_int32),
                                  C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32), C.c_int,
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.pt_host_list_entry.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.pt_host_cell_order.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.pt_sync.argtypes = [C.c_void_p]
     lib.pt_debug_grid.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32),
                                   C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]

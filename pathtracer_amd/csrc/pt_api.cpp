@@ -284,7 +284,7 @@ int prepare(pt_ctx* c) {
 	}
 	// The per-cell lists are built on the device for large scenes (PT_GRID_BUILD=host|device overrides the
 	// choice); the packed cell ranges the device passes use hold 10 bits per axis and 23 bits of entity id.
-	const bool ranges_fit = gd.cell_count[0] <= 1023 && gd.cell_count[1] <= 1023 && gd.cell_count[2] <= 1023 && n < (1 << 23);
+	const bool ranges_fit = gd.cell_count[0] <= 1023 && gd.cell_count[1] <= 1023 && gd.cell_count[2] <= 1023 && (uint32_t)n < ptl::ENTRY_ID_LIMIT;
 	const char* where = getenv("PT_GRID_BUILD");
 	bool grid_on_device = have_grid && ranges_fit && (where ? strcmp(where, "device") == 0 : n >= 4096);
 
@@ -1642,6 +1642,22 @@ int pt_host_grid(const float* records, int n, int hint, int32_t* grid_ints, uint
 		if((int)items.size() > item_capacity) return PT_ERR_LIMIT;
 		if(!items.empty()) memcpy(cell_items, items.data(), items.size() * 4);
 	}
+	return PT_OK;
+}
+
+int pt_host_list_entry(const float centre[3], float radius, uint32_t tag, uint32_t id, uint32_t entry[4], uint32_t* id_back) {
+	if(!centre || !entry || id >= ptl::ENTRY_ID_LIMIT || tag > 511u) return PT_ERR_ARG;
+	ptl::pack_entry(centre[0], centre[1], centre[2], radius, tag, id, entry);
+	if(id_back) *id_back = ptl::entry_id(entry[0], entry[1], entry[2], entry[3]);
+	return PT_OK;
+}
+
+int pt_host_cell_order(const int32_t cell_count[3], const int32_t cell_size[3], int32_t stride[3]) {
+	if(!cell_count || !cell_size || !stride) return PT_ERR_ARG;
+	ptl::GridDev g{};
+	for(int k = 0; k < 3; k++) { g.cnt[k] = cell_count[k]; g.cs[k] = cell_size[k]; }
+	ptl::grid_layout(g);
+	for(int k = 0; k < 3; k++) stride[k] = g.stride[k];
 	return PT_OK;
 }
 

@@ -194,3 +194,41 @@ def test_write_through_store_keeps_its_wait_states():
         text = open(os.path.join(ROOT, "pathtracer_amd", "csrc", name)).read()
         for body in re.findall(r'asm volatile\("([^"]*)"', text):
             assert not re.search(r"\b(global|flat|buffer|scratch|ds)_", body) or body in stores, (name, body)
+
+
+def test_list_entry_keeps_the_id_and_still_encloses_the_entity(core_lib):
+    """The cooperative cast's 16-byte list entry carries the entity's id in bits of the bounding sphere's centre.
+    Whatever the id, the sphere read back must enclose the entity's own (the filter built on it may pass too much,
+    never too little), and kind, neighbour bits and id must come back unchanged."""
+    rng = np.random.default_rng(11)
+    for _ in range(4000):
+        scale = 10.0 ** rng.uniform(-3, 5)
+        centre = (rng.uniform(-1, 1, 3) * scale).astype(np.float32)
+        if rng.random() < 0.1:
+            centre[rng.integers(0, 3)] = 0.0
+        radius = np.float32(10.0 ** rng.uniform(-3, 3))
+        ident = int(rng.integers(0, 1 << 23)) if rng.random() < 0.8 else (1 << 23) - 1
+        tag = int(rng.integers(0, 512))
+        entry = np.zeros(4, np.uint32)
+        back = C.c_uint32(0)
+        assert core_lib.pt_host_list_entry(fptr(centre), float(radius), tag, ident, uptr(entry), C.byref(back)) == 0
+        assert back.value == ident
+        assert int(entry[3]) & 511 == tag
+        got = entry[:3].view(np.float32).astype(np.float64)
+        got_radius = float(np.array([int(entry[3]) & 0xffff0000], np.uint32).view(np.float32)[0])
+        moved = float(np.sqrt(((got - centre.astype(np.float64)) ** 2).sum()))
+        assert got_radius >= float(radius) + moved, (centre, radius, ident, got, got_radius)
+        assert got_radius <= float(radius) * 1.01 + 130 * float(np.abs(centre).max()) * 2.0 ** -23 + 1e-36
+    bad = np.zeros(4, np.uint32)
+    assert core_lib.pt_host_list_entry(fptr(np.zeros(3, np.float32)), 1.0, 0, 1 << 23, uptr(bad), None) != 0
+
+
+def test_cell_order_puts_the_thinnest_cells_first(core_lib):
+    def order(count, size):
+        out = np.zeros(3, np.int32)
+        assert core_lib.pt_host_cell_order(iptr(np.array(count, np.int32)), iptr(np.array(size, np.int32)), iptr(out)) == 0
+        return list(out)
+    assert order((5, 7, 9), (3, 3, 3)) == [1, 5, 35]            # cubes: the reference's order, x fastest
+    assert order((68, 68, 104), (6, 6, 1)) == [104, 104 * 68, 1]
+    assert order((4, 5, 6), (2, 1, 3)) == [5, 1, 20]
+    assert order((4, 5, 6), (2, 2, 1)) == [6, 24, 1]
