@@ -747,7 +747,7 @@ PT_DEV int cast(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface& surf
 #define PT_COOP_CELLS 7
 #endif
 #ifndef PT_COOP_MIN_WALKING
-#define PT_COOP_MIN_WALKING 32
+#define PT_COOP_MIN_WALKING 40
 #endif
 constexpr int COOP_CELLS = PT_COOP_CELLS;               // cells a lane records per segment
 #ifndef PT_COOP_POOL
