@@ -927,11 +927,16 @@ PT_MARK("chunk_intersected");
 		int rel[3];
 		#pragma unroll
 		for(int a = 0; a < 3; a++) {
-			const int cs = sc.grid.cs[a];
-			int k = (int)floorf(pc[a] * sc.grid.inv_cs[a]);                // within one of the true quotient's floor
-			if((float)(k * cs) > pc[a]) k--;
-			else if((float)((k + 1) * cs) <= pc[a]) k++;
-			if((float)(k * cs) == pc[a]) on_bound |= 1u << a;
+			// in floats throughout: a cell bound is coordinate * size, and the product of two integers held exactly rounds like the integer
+			// product converted - the same bound either way, without the integer multiplies (two ordinary instructions each here)
+			const float cs = (float)sc.grid.cs[a];
+			float kf = floorf(pc[a] * sc.grid.inv_cs[a]);                  // within one of the true quotient's floor
+			const float below = kf * cs, above = (kf + 1.0f) * cs;
+			const bool down = below > pc[a], up = !down && above <= pc[a];
+			kf = down ? kf - 1.0f : up ? kf + 1.0f : kf;
+			const float bound = down ? kf * cs : up ? above : below;
+			if(bound == pc[a]) on_bound |= 1u << a;
+			const int k = (int)kf;
 			q[a] = k;
 			rel[a] = k - sc.grid.cmin[a];
 			const int lo_a = (int)((lo >> (10 * a)) & 1023u), hi_a = (int)((hi >> (10 * a)) & 1023u);
