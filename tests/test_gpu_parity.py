@@ -495,7 +495,7 @@ def test_grid_scenes_at_full_size(gpu, name):
     assert np.abs(got.astype(np.float64) - want).mean() < 1e-6
 
 
-@pytest.mark.parametrize("name", ["mixed40", "crowded", "dense2k", "dense30k"])
+@pytest.mark.parametrize("name", ["mixed40", "crowded", "dense2k", "dense30k", "aligned_boxes"])
 def test_grid_built_on_device_equals_host_build(gpu, name, monkeypatch):
     """The device passes (count, scan, fill, order) must give the host build's CSR word for word (ascending
     ids per cell, the reference's append order), the same packed cell ranges, and therefore the same image;
