@@ -75,6 +75,10 @@ enum { CAST_BRUTE = 0, CAST_GRID_LANE = 1, CAST_GRID_COOP = 2 };
 #endif
 // THROUGH: the range sums go through the caches to memory (asynchronous renders, whose frames can be polled while they are
 // traced).  A compile-time choice: as a run-time one it cost the demo frame 2.4 % through register pressure alone.
+}  // namespace
+
+// The trace kernel has a name other units can see: its brute-force variants are compiled as a unit of their own (below).
+namespace ptk {
 template <int MODE, int FEAT, bool THROUGH>
 __global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIMD : FEAT == 0 ? PT_PLAIN_WAVES_PER_SIMD : PT_BRUTE_WAVES_PER_SIMD) void pt_k_trace(ptl::TraceJob job) {
 #ifdef PT_COOP_TIMING
@@ -347,6 +351,26 @@ PT_MARK("shade_end");
 		if(lane == 0) atomicAdd((unsigned long long*)job.stats, (unsigned long long)casts);
 	}
 }
+
+// The brute-force variants run 1.3 % faster when the compiler optimises them for size (-Os), the grid variants 1 % slower.
+// So the library is built from this file twice: once as it stands with -DPT_SPLIT_BRUTE, which only declares the four
+// brute-force variants, and once with -Os -DPT_UNIT_BRUTE, which defines them and nothing else.  Without either macro
+// the file is one unit with everything in it (listings, diagnostic builds).
+#define PT_BRUTE_VARIANTS(PREFIX) \
+	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, 0, false>(ptl::TraceJob); \
+	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, 0, true>(ptl::TraceJob); \
+	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, FEAT_ALL, false>(ptl::TraceJob); \
+	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, FEAT_ALL, true>(ptl::TraceJob);
+#if defined(PT_UNIT_BRUTE)
+PT_BRUTE_VARIANTS()
+#elif defined(PT_SPLIT_BRUTE)
+PT_BRUTE_VARIANTS(extern)
+#endif
+}  // namespace ptk
+using namespace ptk;
+
+#if !defined(PT_UNIT_BRUTE)
+namespace {
 
 // Folds the range sums of every pixel, in range order, into the image (code/raycast.cpp:1263-1270:
 // average of the per-sample clamped colours, clamped again).  A pixel whose ranges do not all carry
@@ -753,3 +777,4 @@ hipError_t launch_assemble(const float* parts, size_t stride, int part_count, in
 }
 
 }  // namespace ptl
+#endif   // !PT_UNIT_BRUTE
