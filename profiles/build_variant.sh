@@ -3,7 +3,7 @@
 # usage: profiles/build_variant.sh <name> [extra hipcc flags...]
 name=$1; shift
 # the brute-force variants of the trace kernel are a unit of their own, optimised for size (as in __graft_entry__.build_core)
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize "$@" -Os -DPT_UNIT_BRUTE \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize "$@" ${BRUTE_OPT:--Os} -DPT_UNIT_BRUTE \
 	-Iinclude -Ipathtracer_amd/csrc -c pathtracer_amd/csrc/pt_kernels.hip -o /tmp/variant_${name}_brute.o -Rpass-analysis=kernel-resource-usage > /tmp/variant_${name}_brute.log 2>&1 || { grep -E "error" /tmp/variant_${name}_brute.log | head -5; exit 1; }
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize "$@" -DPT_SPLIT_BRUTE \
 	-Iinclude -Ipathtracer_amd/csrc /tmp/variant_${name}_brute.o pathtracer_amd/csrc/pt_api.cpp pathtracer_amd/csrc/pt_host.cpp pathtracer_amd/csrc/pt_scene.cpp pathtracer_amd/csrc/pt_kernels.hip pathtracer_amd/csrc/pt_gridbuild.hip \
