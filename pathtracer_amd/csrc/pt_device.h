@@ -862,14 +862,18 @@ PT_DEV void get6(const v2f (&slot)[3], V3& a, V3& b) {
 // Conservative reject: true when the ray's line misses the entity's (slightly enlarged) bounding
 // sphere or the sphere lies wholly behind the origin.  No exact intersector can report a hit then,
 // so skipping the entity does not change any result.  No divide, no square root.
+// This test decides nothing but which entities get the exact test, and its margins are a hundred times the rounding of
+// its arithmetic: it is the one place that uses fused multiply-adds (a third fewer instructions).
+PT_DEV float fdot(V3 a, V3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
 PT_DEV bool sphere_rejects(V3 rp, V3 rd, v4f p0) {
 	V3 l = rp - v3(p0.x, p0.y, p0.z);
-	float dd = dot(rd, rd), dl = dot(rd, l), ll = dot(l, l);
-	float r = p0.w * 1.002f + 1e-3f;
+	float dd = fdot(rd, rd), dl = fdot(rd, l), ll = fdot(l, l);
+	float r = __builtin_fmaf(p0.w, 1.002f, 1e-3f);
 	float r2 = r * r;
-	float slack = 1e-5f * (dl * dl + dd * ll);
-	float disc = dl * dl - dd * (ll - r2);
-	bool may_hit = (disc + slack >= 0) && (dl <= 0 || ll <= r2 * 1.0001f + slack);
+	float dl2 = dl * dl;
+	float slack = 1e-5f * __builtin_fmaf(dd, ll, dl2);
+	float disc = __builtin_fmaf(-dd, ll - r2, dl2);
+	bool may_hit = (disc + slack >= 0) && (dl <= 0 || ll <= __builtin_fmaf(r2, 1.0001f, slack));
 	return !may_hit;
 }
 
