@@ -57,6 +57,8 @@ PT_DEV V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
 PT_DEV V3 operator*(V3 a, float b) { return v3(a.x * b, a.y * b, a.z * b); }
 PT_DEV V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
 PT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// The fused form, for estimates only: nothing whose bits reach a result may use it.
+PT_DEV float fdot(V3 a, V3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
 PT_DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 
 // ---- correctly rounded division and square root, the short way ---------------------------------------
@@ -206,29 +208,32 @@ PT_DEV float hit_sphere(V3 lp, V3 ld, V3 sp, float sr, V3& pos, V3& nrm) {
 
 PT_DEV bool touches_sphere(V3 lp, V3 ld, V3 sp, float sr) {  // lineSphereCollision, code/rt_math.cpp:2361-2373
 	lp = lp - sp;
-	float ll = dot(lp, lp);
+	// The quantities the clear-cut decisions are taken from may be fused: their margins are far above any rounding.  The
+	// reference's own arithmetic is redone, unfused, only where a decision is close (below).
+	float ll = fdot(lp, lp);
 	float rr = sr * sr;
 	// A ray that starts well inside the sphere touches it, whatever its direction: with |lp|^2 < 0.999 r^2 and a
 	// direction no longer than 2, b = d*d - |lp|^2 + r^2 is at least 0.001 r^2 and sqrt(b) exceeds |d| by more than
 	// 1e-4 r, four orders of magnitude above the rounding errors of the reference's float arithmetic.  (The bounding
 	// sphere of a ground box holds nearly every ray origin of a scene.)  Skipped only when the whole wavefront agrees.
-	if(__ballot(!(ll < 0.999f * rr && dot(ld, ld) <= 4.0f)) == 0) return true;
-	float d = dot(ld, lp);
+	if(__ballot(!(ll < 0.999f * rr && fdot(ld, ld) <= 4.0f)) == 0) return true;
+	float d = fdot(ld, lp);
 	// The reference takes two square roots: b = d*d - length(lp)^2 + sr*sr must not be negative, and
 	// -d + sqrt(b) must not be negative, which is the case exactly when d <= 0 or sr*sr >= length(lp)^2.
 	// Both decisions are clear-cut for almost every ray: when the quantities are further from zero
 	// than a margin far above their rounding errors, the answer is known without the roots.
-	float margin = 1e-5f * (d * d + ll + rr);
-	float b_est = d * d - ll + rr;
+	float margin = 1e-5f * (__builtin_fmaf(d, d, ll) + rr);
+	float b_est = __builtin_fmaf(d, d, rr - ll);
 	// (plain & and |: every operand is a comparison of values at hand, cheaper to evaluate than to branch around)
 	const bool clear_miss = (b_est < -margin) | ((d > 0) & (ll - rr > margin));
 	const bool clear_hit = (b_est > margin) & ((d < 0) | (rr - ll > margin));
 	bool touches = clear_hit;
 	if(__ballot(!clear_miss && !clear_hit) != 0) {            // wave-uniform: the roots are skipped only if no lane needs them
-		float l = sqrtf(ll);                                  // length(lp): the same sum of squares
-		float b = d * d - l * l + sr * sr;
+		float l = sqrtf(dot(lp, lp));                         // length(lp)
+		float dx = dot(ld, lp);
+		float b = dx * dx - l * l + sr * sr;
 		bool exact = false;
-		if(b >= 0) exact = !(-(dot(ld, lp)) + sqrtf(b) < 0);
+		if(b >= 0) exact = !(-dx + sqrtf(b) < 0);
 		if(!clear_miss && !clear_hit) touches = exact;
 	}
 	return touches;
@@ -864,7 +869,6 @@ PT_DEV void get6(const v2f (&slot)[3], V3& a, V3& b) {
 // so skipping the entity does not change any result.  No divide, no square root.
 // This test decides nothing but which entities get the exact test, and its margins are a hundred times the rounding of
 // its arithmetic: it is the one place that uses fused multiply-adds (a third fewer instructions).
-PT_DEV float fdot(V3 a, V3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
 PT_DEV bool sphere_rejects(V3 rp, V3 rd, v4f p0) {
 	V3 l = rp - v3(p0.x, p0.y, p0.z);
 	float dd = fdot(rd, rd), dl = fdot(rd, l), ll = fdot(l, l);
