@@ -205,9 +205,17 @@ class Env:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if self.world_size != gpus:
             raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={self.world_size}: launch with torch.distributed.run --nproc-per-node {gpus}")
+        # Rehearsal of the multi-rank path on a box with fewer GPUs than ranks: PT_BENCH_BACKEND=gloo lets several ranks
+        # share a GPU (RCCL refuses two ranks on one device); the numbers of such a run mean nothing, the code path is the same.
+        backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
+        if backend != "nccl":
+            self.local_rank %= max(1, torch.cuda.device_count())
         torch.cuda.set_device(self.local_rank)
         if self.world_size > 1:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(backend)
 
     def max_over_ranks(self, value, op="max"):
         if self.world_size == 1:
@@ -320,6 +328,9 @@ def main():
     ap.add_argument("--ranges", type=int, default=0, help="pt_settings.sample_ranges (0 = the library's choice)")
     args = ap.parse_args()
 
+    if os.environ.get("PT_BENCH_HANG_TRACE"):          # rehearsals: where every thread stands after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["PT_BENCH_HANG_TRACE"]), exit=True)
     env = Env(args.gpus)
     torch, dist, world_size, rank = env.torch, env.dist, env.world_size, env.rank
     m = measure(env, args.workload, args.steps, args.warmup, not args.no_prewarm, args.ranges)

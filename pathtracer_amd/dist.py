@@ -21,6 +21,18 @@ def gather_parts(mine, gathered, stride, rank, world_size, root=0, group=None):
     if world_size == 1:
         gathered[:stride].copy_(mine)
         return
+    if mine.is_cuda and dist.get_backend(group) == "gloo":
+        # several ranks sharing one GPU in a rehearsal: gloo moves host tensors; the device tensors are staged through
+        # the host in stream order (the copies below run on the current stream and wait for it)
+        host = mine.cpu()
+        if rank == root:
+            parts = [torch.empty(stride, dtype=mine.dtype) for _ in range(world_size)]
+            dist.gather(host, parts, dst=root, group=group)
+            for i, part in enumerate(parts):
+                gathered[i * stride:(i + 1) * stride].copy_(part)
+        else:
+            dist.gather(host, None, dst=root, group=group)
+        return
     if rank == root:
         views = [gathered[i * stride:(i + 1) * stride] for i in range(world_size)]
         dist.gather(mine, views, dst=root, group=group)

@@ -42,3 +42,27 @@ def test_partitions_traced_by_separate_processes(tmp_path):
     for frame in got[:3]:
         assert (frame.view(np.uint32) == whole.view(np.uint32)).all()
     assert got[3, 0, 0, 0] == np.float32(paths)
+
+
+def test_bench_line_of_two_ranks_on_the_one_gpu():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per partition), rehearsed with two ranks
+    on the one GPU over gloo: the line must come from rank 0 alone, count the whole frame's paths and name both ranks."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PT_BENCH_BACKEND="gloo", PT_BENCH_HANG_TRACE="150")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--no-secondary", "--no-prewarm"]
+    try:
+        done = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=200)
+    except subprocess.TimeoutExpired:
+        pytest.fail("the two-rank bench hung")
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [json.loads(l) for l in done.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "strong"
+    assert line["config"]["paths_per_frame"] == 139622400          # both partitions of the 1080p / 64 spp frame
+    assert line["value"] > 0 and line["roofline"]["kernel_ms"] > 0
