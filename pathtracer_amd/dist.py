@@ -41,12 +41,15 @@ def gather_parts(mine, gathered, stride, rank, world_size, root=0, group=None):
 
 
 class FramePipeline:
-    """Frames of a partitioned render with the gather off the critical path: the tile buffers are
-    double-buffered, the trace of frame i+1 runs on the main stream while the gather and the assemble of
-    frame i run on a side stream.  `renderers` are this process's contexts (one per owned partition; one
-    in the one-process-per-GPU case), `parts` their partition indices."""
+    """Frames of a partitioned render with the gather off the critical path: the tile buffers come in a ring of
+    `depth`, the traces of the following frames run on the main stream while the gather and the assemble of
+    frame i run on a side stream.  Three buffers, not two: the trace kernel is persistent and holds every wavefront
+    slot of its GPU until its frame ends, so the collective of frame i only gets onto the GPU in the tail of trace
+    i+1; with two buffers trace i+2 would have to wait for it (and for the assemble) right there, with three it
+    waits for the collective of frame i-1, which had a whole frame to finish.  `renderers` are this process's contexts
+    (one per owned partition; one in the one-process-per-GPU case), `parts` their partition indices."""
 
-    def __init__(self, renderers, parts, part_count, width, height, rank=0, world_size=1, group=None, keep_frames=0):
+    def __init__(self, renderers, parts, part_count, width, height, rank=0, world_size=1, group=None, keep_frames=0, depth=3):
         self.renderers, self.parts, self.part_count = renderers, parts, part_count
         self.width, self.height, self.rank, self.world_size, self.group = width, height, rank, world_size, group
         self.stride = partition_stride(width, height, part_count)
@@ -57,21 +60,22 @@ class FramePipeline:
         self.main = torch.cuda.Stream()
         self.side = torch.cuda.Stream()
         local = len(parts)
-        self.mine = [torch.zeros(local * self.stride, dtype=torch.float32, device="cuda") for _ in range(2)]
+        self.depth = depth
+        self.mine = [torch.zeros(local * self.stride, dtype=torch.float32, device="cuda") for _ in range(depth)]
         root = rank == 0
-        self.gathered = [torch.empty(part_count * self.stride, dtype=torch.float32, device="cuda") if root else None for _ in range(2)]
+        self.gathered = [torch.empty(part_count * self.stride, dtype=torch.float32, device="cuda") if root else None for _ in range(depth)]
         self.image = torch.empty(height * width * 3, dtype=torch.float32, device="cuda") if root else None
-        self.traced = [torch.cuda.Event() for _ in range(2)]
-        self.drained = [torch.cuda.Event() for _ in range(2)]
+        self.traced = [torch.cuda.Event() for _ in range(depth)]
+        self.drained = [torch.cuda.Event() for _ in range(depth)]
         self.frame = 0
         # tests: a copy of every assembled frame, taken on the side stream without stopping the pipeline
         self.kept = [torch.empty(height * width * 3, dtype=torch.float32, device="cuda") for _ in range(keep_frames)] if root else []
         torch.cuda.synchronize()         # the buffers above were filled on the default stream
 
     def step(self):
-        b = self.frame & 1
-        if self.frame >= 2:
-            self.main.wait_event(self.drained[b])          # the gather that read mine[b] two frames ago
+        b = self.frame % self.depth
+        if self.frame >= self.depth:
+            self.main.wait_event(self.drained[b])          # the gather that read mine[b] `depth` frames ago
         for k, r in enumerate(self.renderers):
             r.trace(d_rgb=self.mine[b][k * self.stride:].data_ptr(), stream=self.main.cuda_stream, sync=False)
         self.traced[b].record(self.main)
