@@ -245,7 +245,8 @@ int pt_cast_rays_noalloc(pt_ctx* ctx, const float* origins, const float* dirs, i
  * (normVec3 code/rt_math.cpp:2166-2168, lenVec3 :2130-2164, Vec3 / float :2093) with shorter instruction
  * sequences than the compiler's whenever the operands allow it; every result must still be the IEEE
  * one.  op 0: out[i] = sqrt(a[i]); op 1: out[3i..] = a[3i..] / b[i]; op 2: out[3i..] = a[3i..] /
- * length(a[3i..]); op 3: out[3i..] = a[3i..] / (float)pi.  Host pointers.  pt_debug_arith_sweep runs
+ * length(a[3i..]); op 3: out[3i..] = a[3i..] / (float)pi; op 4: out[3i..] = 1 / a[3i..] (the slab test's
+ * reciprocals, code/rt_math.cpp lineBoxIntersection).  Host pointers.  pt_debug_arith_sweep runs
  * `count` (at most 2^32) consecutive bit patterns from first_bits through the same op on the device,
  * with derived companions, and counts results whose bits differ from the compiler's own sequences. */
 int pt_debug_arith(pt_ctx* ctx, int op, const float* a, const float* b, int n, float* out);

@@ -1419,7 +1419,7 @@ int pt_pick_rays(pt_ctx* c, const float* origins, const float* dirs, int n, int3
 
 int pt_debug_arith(pt_ctx* c, int op, const float* a, const float* b, int n, float* out) {
 	if(!c) return PT_ERR_ARG;
-	if(op < 0 || op > 3 || n < 0 || (n > 0 && (!a || !out || (op == 1 && !b)))) return fail(c, PT_ERR_ARG, "bad argument");
+	if(op < 0 || op > 4 || n < 0 || (n > 0 && (!a || !out || (op == 1 && !b)))) return fail(c, PT_ERR_ARG, "bad argument");
 	if(n == 0) return PT_OK;
 	PT_HIP(c, hipSetDevice(c->device));
 	const size_t per = op == 0 ? 1 : 3, va = (size_t)n * per * 4, vb = (size_t)n * 4;
@@ -1436,7 +1436,7 @@ int pt_debug_arith(pt_ctx* c, int op, const float* a, const float* b, int n, flo
 
 int pt_debug_arith_sweep(pt_ctx* c, int op, uint32_t first_bits, uint64_t count, uint64_t* mismatches) {
 	if(!c) return PT_ERR_ARG;
-	if(op < 0 || op > 3 || !mismatches || count > (1ull << 32)) return fail(c, PT_ERR_ARG, "bad argument");
+	if(op < 0 || op > 4 || !mismatches || count > (1ull << 32)) return fail(c, PT_ERR_ARG, "bad argument");
 	PT_HIP(c, hipSetDevice(c->device));
 	PT_HIP(c, c->scratch.reserve(1024));
 	PT_HIP(c, hipMemsetAsync(c->scratch.p, 0, 8, c->stream));

@@ -110,6 +110,23 @@ PT_DEV V3 operator/(V3 a, float b) {
 	if(!(min3abs(a) >= kPlainLo && sum3abs(a) <= kPlainHi && m >= kPlainLo && m <= kPlainHi)) q = v3(a.x / b, a.y / b, a.z / b);
 	return q;
 }
+// 1 / a.x, 1 / a.y, 1 / a.z.  The compiler's own form stays behind a fence for the lanes that need it: its operands are
+// a ray's direction, which does not change over a cast, and without the fence the compiler lifts the long form out of its
+// guard to run it once for every ray.
+PT_DEV V3 recip3(V3 a) {
+#ifdef PT_LONG_RECIP
+	return v3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z);
+#else
+	const float rx = recip_near(a.x), ry = recip_near(a.y), rz = recip_near(a.z);
+	V3 q = v3(quotient(1.0f, a.x, rx), quotient(1.0f, a.y, ry), quotient(1.0f, a.z, rz));
+	if(!(min3abs(a) >= kPlainLo && sum3abs(a) <= kPlainHi)) {
+		V3 b = a;
+		asm volatile("" : "+v"(b.x), "+v"(b.y), "+v"(b.z));
+		q = v3(1.0f / b.x, 1.0f / b.y, 1.0f / b.z);
+	}
+	return q;
+#endif
+}
 PT_DEV float length(V3 a) { return sq_root(a.x * a.x + a.y * a.y + a.z * a.z); }
 // a / length(a): divides, never multiplies by a reciprocal (code/rt_math.cpp:2166-2168).  Components of at
 // least 2^-40 and a sum of squares of at most 2^80 make the root and all three quotients ordinary.
@@ -240,8 +257,11 @@ PT_DEV bool touches_sphere(V3 lp, V3 ld, V3 sp, float sr) {  // lineSphereCollis
 }
 
 // The slab test of lineBoxIntersection once the box's corners are known.
-PT_DEV float hit_slabs(V3 lp, V3 ld, V3 bmin, V3 bmax, V3& pos, V3& nrm) {
-	float fx = 1.0f / ld.x, fy = 1.0f / ld.y, fz = 1.0f / ld.z;
+// (`inv`: the reciprocals of ld's components where the caller has them at hand - a cast that tests several boxes
+// with one ray works them out once.)
+PT_DEV float hit_slabs(V3 lp, V3 ld, V3 bmin, V3 bmax, V3& pos, V3& nrm, const V3* inv = nullptr) {
+	const V3 f = inv ? *inv : recip3(ld);
+	const float fx = f.x, fy = f.y, fz = f.z;
 	float t1 = (bmin.x - lp.x) * fx;
 	float t2 = (bmax.x - lp.x) * fx;
 	float t3 = (bmin.y - lp.y) * fy;
@@ -262,9 +282,9 @@ PT_DEV float hit_slabs(V3 lp, V3 ld, V3 bmin, V3 bmax, V3& pos, V3& nrm) {
 	nrm.z = on_xy ? 0.0f : (f5 ? -1.0f : (f6 ? 1.0f : 0.0f));
 	return distance;
 }
-PT_DEV float hit_box(V3 lp, V3 ld, V3 bpos, V3 bdim, V3& pos, V3& nrm) {
+PT_DEV float hit_box(V3 lp, V3 ld, V3 bpos, V3 bdim, V3& pos, V3& nrm, const V3* inv = nullptr) {
 	V3 half = bdim * 0.5f;            // the same floats as bdim / 2
-	return hit_slabs(lp, ld, bpos - half, bpos + half, pos, nrm);
+	return hit_slabs(lp, ld, bpos - half, bpos + half, pos, nrm, inv);
 }
 
 PT_DEV float hit_cylinder(V3 p, V3 d, V3& pos, V3& nrm) {
@@ -379,7 +399,7 @@ PT_DEV int kind_of(int type, bool rotated, bool even) {
 }
 
 template <int KIND>
-PT_DEV float intersect_kind(const GeoRef& g, v4f p0, v4f p3, V3 rp, V3 rd, V3& pos, V3& nrm) {
+PT_DEV float intersect_kind(const GeoRef& g, v4f p0, v4f p3, V3 rp, V3 rd, V3& pos, V3& nrm, const V3* inv = nullptr) {
 	V3 opos = v3(p0.x, p0.y, p0.z);
 	V3 dim = v3(p3.x, p3.y, p3.z);
 	float distance = -1;
@@ -389,7 +409,7 @@ PT_DEV float intersect_kind(const GeoRef& g, v4f p0, v4f p3, V3 rp, V3 rd, V3& p
 	} else if(KIND == KIND_BOX) {
 		// corners of an unrotated box (pos -/+ dim / 2), kept by the host in two slots such a box never reads
 		v4f lo = g.plane(G_BOX_LO), hi = g.plane(G_BOX_HI);
-		distance = hit_slabs(rp, rd, v3(lo.x, lo.y, lo.z), v3(hi.x, hi.y, hi.z), pos, nrm);
+		distance = hit_slabs(rp, rd, v3(lo.x, lo.y, lo.z), v3(hi.x, hi.y, hi.z), pos, nrm, inv);
 	} else if(KIND == KIND_BOX_ROTATED) {
 		v4f ri = g.plane(G_ROTINV);
 		V3 lp = rp - opos;
@@ -547,14 +567,14 @@ enum { FEAT_UNIT_KINDS = 1,     // rotated boxes, ellipsoids, cylinders, cones: 
 
 // getIntersection (code/raycast.cpp:813-893).  p0 = plane G_POS already loaded by the caller.
 template <int FEAT = FEAT_ALL>
-PT_DEV float intersect(const GeoRef& g, v4f p0, V3 rp, V3 rd, V3& pos, V3& nrm) {
+PT_DEV float intersect(const GeoRef& g, v4f p0, V3 rp, V3 rd, V3& pos, V3& nrm, const V3* inv = nullptr) {
 	v4f p3 = g.plane(G_DIM);
 	int tf = __float_as_int(p3.w);
 	int type = tf & 0xff;
 	if(type > PT_GEOM_CONE) return -1;
 	switch(kind_of(type, (tf >> 8) & FLAG_ROTATED, (tf >> 8) & FLAG_EVEN)) {
 		case KIND_SPHERE: return intersect_kind<KIND_SPHERE>(g, p0, p3, rp, rd, pos, nrm);
-		case KIND_BOX: return intersect_kind<KIND_BOX>(g, p0, p3, rp, rd, pos, nrm);
+		case KIND_BOX: return intersect_kind<KIND_BOX>(g, p0, p3, rp, rd, pos, nrm, inv);
 		default: break;
 	}
 	if(!(FEAT & FEAT_UNIT_KINDS)) return -1;          // the scene holds no such entity
@@ -577,7 +597,7 @@ struct Walk {
 
 // Entry test of spatialGridTraverseInit: false when the ray never reaches the grid ("outside").
 // On success `p` is the point traversal starts from.
-PT_DEV bool grid_entry(const Grid& g, V3 rp, V3 rd, V3& p) {
+PT_DEV bool grid_entry(const Grid& g, V3 rp, V3 rd, V3& p, const V3* inv = nullptr) {
 	V3 bmin = v3((float)(g.cmin[0] * g.cs[0]), (float)(g.cmin[1] * g.cs[1]), (float)(g.cmin[2] * g.cs[2]));
 	V3 bmax = v3((float)((g.cmin[0] + g.cnt[0]) * g.cs[0]), (float)((g.cmin[1] + g.cnt[1]) * g.cs[1]), (float)((g.cmin[2] + g.cnt[2]) * g.cs[2]));
 	p = rp;
@@ -585,7 +605,7 @@ PT_DEV bool grid_entry(const Grid& g, V3 rp, V3 rd, V3& p) {
 		V3 bdim = bmax - bmin;
 		V3 bpos = bmin + bdim * 0.5f;     // the same floats as bdim / 2
 		V3 ip, in;
-		float distance = hit_box(rp, rd, bpos, bdim, ip, in);
+		float distance = hit_box(rp, rd, bpos, bdim, ip, in, inv);
 		if(distance != -1) p = ip + rd * 0.0001f;
 		else return false;
 	}
@@ -672,7 +692,8 @@ PT_DEV Surface surface_of(const Scene& sc, int index) {
 template <int FEAT = FEAT_ALL, bool GRID_GATE = true>
 PT_DEV int cast_all(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface& surf) {
 	V3 entry;
-	if(GRID_GATE && !grid_entry(sc.grid, rp, rd, entry)) return 0;   // outside: only planes would be tested, and there are none
+	const V3 inv = recip3(rd);          // for the grid's box and every upright box of the scene
+	if(GRID_GATE && !grid_entry(sc.grid, rp, rd, entry, &inv)) return 0;   // outside: only planes would be tested, and there are none
 	int id = 0;
 	float best = 3.402823466e+38f;
 	for(int i = 0; i < sc.n; i++) {
@@ -680,7 +701,7 @@ PT_DEV int cast_all(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface& 
 		v4f p0 = g.plane(G_POS);
 		if(touches_sphere(rp, rd, v3(p0.x, p0.y, p0.z), p0.w)) {
 			V3 p, q;
-			float distance = intersect<FEAT>(g, p0, rp, rd, p, q);
+			float distance = intersect<FEAT>(g, p0, rp, rd, p, q, &inv);
 			if(distance > 0 && distance < best) {
 				best = distance;
 				id = i + 1;

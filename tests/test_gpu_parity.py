@@ -872,13 +872,15 @@ def test_short_division_and_root_are_ieee(gpu):
         x[::5] = a[::5, 1]                                   # negative arguments too
         got = gpu.arith(0, x)
         _assert_same(got, np.sqrt(x), "square root against IEEE", x)
+        got = gpu.arith(4, a)
+        _assert_same(got, np.float32(1) / a, "1 / Vec3 against IEEE division", a)
         ss = (a[:, 0] * a[:, 0] + a[:, 1] * a[:, 1]) + a[:, 2] * a[:, 2]
         length = np.sqrt(ss)
         got = gpu.arith(2, a)
         _assert_same(got, a / length[:, None], "normalise against a / sqrt(x*x + y*y + z*z)", a)
 
 
-@pytest.mark.parametrize("op", [0, 1, 2, 3])
+@pytest.mark.parametrize("op", [0, 1, 2, 3, 4])
 def test_short_forms_equal_the_compilers_over_all_bit_patterns(gpu, op):
     # on the device: every one of the 2^32 float bit patterns as (first) operand, short form against the long one
     assert gpu.arith_sweep(op, 0, 1 << 32) == 0
