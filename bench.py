@@ -299,6 +299,18 @@ def measure(env, name, steps, warmup, prewarm_enabled=True, ranges=0):
             "dt": env.max_over_ranks(dt), "paths": env.max_over_ranks(stats.paths, "sum"), "kernel_ms": env.max_over_ranks(kstats.dominant_kernel_ms)}
 
 
+def measured_traffic(name, world_size):
+    """HBM bytes per launch of the trace kernel from the committed counter passes (profiles/summarise.py), or None."""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+    except Exception:
+        return None, None
+    for entry in [pm] + list(pm.get("also", {}).values()):
+        if entry.get("workload") == name and entry.get("n_gpus", 1) == world_size:
+            return entry.get("hbm_bytes_per_launch"), entry.get("source")
+    return None, None
+
+
 def roofline_block(name, m, world_size, flops_per_path=None):
     """fp32 VALU roofline of pt_k_trace for one measurement: neither HBM (0.03 TB/s moved) nor MFMA (no dense contraction
     in a path tracer) bounds this kernel, the vector ALUs' instruction issue does, so the peak quoted is the vector fp32 peak."""
@@ -313,6 +325,10 @@ def roofline_block(name, m, world_size, flops_per_path=None):
         roof["achieved"] = flops_per_path * m["paths"] / world_size / (m["kernel_ms"] * 1e-3) / 1e12
         roof["frac"] = roof["achieved"] / PEAK_FP32_VALU_TFLOPS
         roof["frac_of_scalar_issue_peak"] = roof["achieved"] / PEAK_SCALAR_ISSUE_TFLOPS
+    traffic, source = measured_traffic(name, world_size)
+    if traffic is not None:
+        roof["traffic"] = traffic
+        roof["traffic_source"] = source
     return roof
 
 
@@ -395,15 +411,6 @@ def main():
             out["cpu_baseline"] = base
             flops_per_path = flops_from_counters(counters) / max(1, counters["paths"])
         roof = roofline_block(args.workload, m, world_size, flops_per_path)
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
-            try:
-                pm = json.load(open(pmc))
-                if pm.get("workload") == args.workload and pm.get("n_gpus", 1) == world_size:
-                    roof["traffic"] = pm.get("hbm_bytes_per_launch")
-                    roof["traffic_source"] = pm.get("source")
-            except Exception:
-                pass
         out["roofline"] = roof
         if end_to_end is not None:
             out["end_to_end"] = end_to_end
