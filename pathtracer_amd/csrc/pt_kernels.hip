@@ -530,7 +530,7 @@ __global__ __launch_bounds__(kBlock) void pt_k_arith(int op, const float* a, con
 	if(op == ARITH_OVER) q = v / b[i];
 	else if(op == ARITH_NORMALISE) q = normalise(v);
 	else if(op == ARITH_RECIP) q = recip3(v);
-	else q = v / 3.14159274101257324f;
+	else q = over_pi(v);
 	out[3 * i] = q.x; out[3 * i + 1] = q.y; out[3 * i + 2] = q.z;
 }
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {     // a bijective scrambler: related operands from one counter
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(kBlock) void pt_k_arith_sweep(int op, uint32_t firs
 			if(op == ARITH_OVER) { const float d = near ? x * (float)(1 + (g & 255u)) * 0.37f : __uint_as_float(mix32(h)); q = v / d; w = v3(long_div(x, d), long_div(y, d), long_div(z, d)); }
 			else if(op == ARITH_RECIP) { q = recip3(v); w = v3(long_div(1.0f, x), long_div(1.0f, y), long_div(1.0f, z)); }
 			else if(op == ARITH_NORMALISE) { q = normalise(v); const float l = long_sqrt(x * x + y * y + z * z); w = v3(long_div(x, l), long_div(y, l), long_div(z, l)); }
-			else { const float pi = 3.14159274101257324f; q = v / pi; w = v3(long_div(x, pi), long_div(y, pi), long_div(z, pi)); }
+			else { const float pi = 3.14159274101257324f; q = over_pi(v); w = v3(long_div(x, pi), long_div(y, pi), long_div(z, pi)); }
 			bad += (same_bits(q.x, w.x) && same_bits(q.y, w.y) && same_bits(q.z, w.z)) ? 0 : 1;
 		}
 	}
