@@ -281,9 +281,10 @@ PT_MARK("camera_begin");
 			v2f s = sc.samples[sample_base + si];
 			// the cooperative cast is short of registers: it recomputes what the other variants keep per pixel
 			const V3 from = MODE == CAST_GRID_COOP ? pixel_origin_tab(job, fr, px, py) : origin;
-			const uint64_t round = (uint64_t)pass;
 			camera_ray(sc, fr, from, s, lens + si, rp, rd);
-			sample_stream(fr, px, py, si, round, rng);
+#ifdef PT_EAGER_SEED
+			sample_stream(fr, px, py, si, (uint64_t)pass, rng);
+#endif
 			att = v3(1, 1, 1);
 			col = v3(0, 0, 0);
 			bounce = 0;
@@ -316,6 +317,11 @@ PT_MARK("cast_begin");
 PT_MARK("cast_end");
 		casts += (uint32_t)__popcll(__ballot(landed));
 		if(landed) {
+#ifndef PT_EAGER_SEED
+			// The sample's random stream is set up when its path first lands on an entity: a path that leaves into the sky
+			// draws no number (nearly half the paths of the demo frame), and nothing between the camera and this point draws one.
+			if(id != 0 && bounce == 0) sample_stream(fr, px, py, si, (uint64_t)pass, rng);
+#endif
 			bool alive = shade<FEAT>(sc, fr, id, surf, hp, hn, bounce, rp, rd, att, col, rng);
 			bounce++;
 			if(!alive || bounce >= max_bounces) {
