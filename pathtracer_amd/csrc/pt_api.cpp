@@ -541,7 +541,12 @@ int trace(pt_ctx* c, float* d_rgb, hipStream_t stream, bool sync, bool write_thr
 	// (PT_EVENT_EVERY=n changes the eight, 1 times every launch).
 	static const int every = getenv("PT_EVENT_EVERY") ? atoi(getenv("PT_EVENT_EVERY")) : 8;
 	bool timed = every <= 1 || (c->serial % (uint32_t)every) == 0;
-	if(!timed) { std::lock_guard<std::mutex> l(c->mu); timed = c->pending.size() < 4; }
+	{
+		// a caller that never reads the statistics out must not pile up events: past 256 unread launches none is timed
+		std::lock_guard<std::mutex> l(c->mu);
+		if(!timed) timed = c->pending.size() < 4;
+		else if(c->pending.size() >= 256) timed = false;
+	}
 	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
 	if(timed) {
 		e0 = take_event(c); e1 = take_event(c); e2 = take_event(c);

@@ -804,6 +804,22 @@ def test_abort_leaves_unfinished_pixels_alone_and_snapshots_grow(gpu):
     r.close()
 
 
+def test_unread_launches_do_not_pile_up_events(gpu):
+    # a caller that traces without ever reading the statistics out: the timed launches stop at 256 pending ones
+    world, objs = scenes.default_scene()
+    r = api.Renderer(0)
+    r.prepare(world, objs, api.default_settings(64, 48, 16, 4, seed=1))
+    for _ in range(4000):
+        r.trace(sync=False)
+    r.sync()
+    st = r.stats()
+    assert 4 <= st.trace_launches <= 256
+    r.trace(sync=False)                     # and timing goes on after the read-out
+    r.sync()
+    assert r.stats().trace_launches == 1
+    r.close()
+
+
 def test_argument_errors(gpu):
     world, objs = scenes.default_scene()
     bad = make_object((0, 0, 0), (1, 1, 1), api.PT_GEOM_PLANE)
