@@ -16,8 +16,14 @@ src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 
+def newest(pattern):
+    """gpurun merges a run's files into what earlier runs left: of several runs' files only the latest counts."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
 rows = []
-for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
+for f in newest(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
     rows += list(csv.DictReader(open(f)))
 with open(os.path.join(dst, "kernel_stats.csv"), "w", newline="") as out:
     w = csv.writer(out)
@@ -26,7 +32,7 @@ with open(os.path.join(dst, "kernel_stats.csv"), "w", newline="") as out:
         w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
 
 acc = collections.defaultdict(list)
-for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
+for f in [g for d in glob.glob(os.path.join(src, "pmc_*")) if os.path.isdir(d) for g in newest(os.path.join(d, "*", "*counter_collection.csv"))]:
     for r in csv.DictReader(open(f)):
         acc[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
 with open(os.path.join(dst, "pmc_summary.csv"), "w", newline="") as out:
