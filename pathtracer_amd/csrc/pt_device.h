@@ -72,6 +72,13 @@ PT_DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x *
 // compiler's form cannot (its scaling depends on each numerator).  The functions below run that core
 // for every lane and redo the compiler's full sequence for the lanes whose operands are not ordinary
 // (a branch the wavefront skips when there are none).
+// The long forms are for the rare lane: told so, the compiler lays them out behind the loop, and the short form's path runs
+// straight on instead of jumping over them.
+#ifdef PT_NO_RARE_HINT
+#define PT_RARE(c) (c)
+#else
+#define PT_RARE(c) __builtin_expect(!!(c), 0)
+#endif
 constexpr float kPlainLo = 0x1p-40f, kPlainHi = 0x1p40f;      // magnitudes the short forms accept
 PT_DEV float min3abs(V3 a) { return __builtin_fminf(__builtin_fminf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z)); }
 // An upper bound of the three magnitudes that is NaN when any of them is (a three-operand maximum drops
@@ -99,7 +106,7 @@ PT_DEV float root_core(float x) {                    // sqrt of an ordinary x: v
 }
 PT_DEV float sq_root(float x) {
 	float s = root_core(x);
-	if(!(x >= 0x1p-90f && x <= 0x1p100f)) s = sqrtf(x);
+	if(PT_RARE(!(x >= 0x1p-90f && x <= 0x1p100f))) s = sqrtf(x);
 	return s;
 }
 // Three quotients with one denominator.
@@ -107,7 +114,7 @@ PT_DEV V3 operator/(V3 a, float b) {
 	const float r = recip_near(b);
 	V3 q = v3(quotient(a.x, b, r), quotient(a.y, b, r), quotient(a.z, b, r));
 	const float m = __builtin_fabsf(b);
-	if(!(min3abs(a) >= kPlainLo && sum3abs(a) <= kPlainHi && m >= kPlainLo && m <= kPlainHi)) q = v3(a.x / b, a.y / b, a.z / b);
+	if(PT_RARE(!(min3abs(a) >= kPlainLo && sum3abs(a) <= kPlainHi && m >= kPlainLo && m <= kPlainHi))) q = v3(a.x / b, a.y / b, a.z / b);
 	return q;
 }
 // 1 / a.x, 1 / a.y, 1 / a.z.  The compiler's own form stays behind a fence for the lanes that need it: its operands are
@@ -119,7 +126,7 @@ PT_DEV V3 recip3(V3 a) {
 #else
 	const float rx = recip_near(a.x), ry = recip_near(a.y), rz = recip_near(a.z);
 	V3 q = v3(quotient(1.0f, a.x, rx), quotient(1.0f, a.y, ry), quotient(1.0f, a.z, rz));
-	if(!(min3abs(a) >= kPlainLo && sum3abs(a) <= kPlainHi)) {
+	if(PT_RARE(!(min3abs(a) >= kPlainLo && sum3abs(a) <= kPlainHi))) {
 		V3 b = a;
 		asm volatile("" : "+v"(b.x), "+v"(b.y), "+v"(b.z));
 		q = v3(1.0f / b.x, 1.0f / b.y, 1.0f / b.z);
@@ -139,7 +146,7 @@ PT_DEV V3 over_pi(V3 a) {
 #else
 	V3 q = a * r;
 	q = v3(__builtin_fmaf(__builtin_fmaf(-pi, q.x, a.x), r, q.x), __builtin_fmaf(__builtin_fmaf(-pi, q.y, a.y), r, q.y), __builtin_fmaf(__builtin_fmaf(-pi, q.z, a.z), r, q.z));
-	if(!(min3abs(a) >= kPlainLo && sum3abs(a) <= kPlainHi)) q = v3(a.x / pi, a.y / pi, a.z / pi);
+	if(PT_RARE(!(min3abs(a) >= kPlainLo && sum3abs(a) <= kPlainHi))) q = v3(a.x / pi, a.y / pi, a.z / pi);
 	return q;
 #endif
 }
@@ -151,7 +158,7 @@ PT_DEV V3 normalise(V3 a) {
 	float l = root_core(ss);
 	const float r = recip_near(l);
 	V3 q = v3(quotient(a.x, l, r), quotient(a.y, l, r), quotient(a.z, l, r));
-	if(!(min3abs(a) >= kPlainLo && ss <= 0x1p80f)) {
+	if(PT_RARE(!(min3abs(a) >= kPlainLo && ss <= 0x1p80f))) {
 		l = sqrtf(ss);
 		q = v3(a.x / l, a.y / l, a.z / l);
 	}
@@ -261,7 +268,7 @@ PT_DEV bool touches_sphere(V3 lp, V3 ld, V3 sp, float sr) {  // lineSphereCollis
 	const bool clear_miss = (b_est < -margin) | ((d > 0) & (ll - rr > margin));
 	const bool clear_hit = (b_est > margin) & ((d < 0) | (rr - ll > margin));
 	bool touches = clear_hit;
-	if(__ballot(!clear_miss && !clear_hit) != 0) {            // wave-uniform: the roots are skipped only if no lane needs them
+	if(PT_RARE(__ballot(!clear_miss && !clear_hit) != 0)) {            // wave-uniform: the roots are skipped only if no lane needs them
 		float l = sqrtf(dot(lp, lp));                         // length(lp)
 		float dx = dot(ld, lp);
 		float b = dx * dx - l * l + sr * sr;
