@@ -79,6 +79,13 @@ PT_DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x *
 #else
 #define PT_RARE(c) __builtin_expect(!!(c), 0)
 #endif
+#ifdef PT_NO_RARE2
+#define PT_RARE2(c) (c)
+#define PT_OFTEN2(c) (c)
+#else
+#define PT_RARE2(c) __builtin_expect(!!(c), 0)
+#define PT_OFTEN2(c) __builtin_expect(!!(c), 1)
+#endif
 constexpr float kPlainLo = 0x1p-40f, kPlainHi = 0x1p40f;      // magnitudes the short forms accept
 PT_DEV float min3abs(V3 a) { return __builtin_fminf(__builtin_fminf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z)); }
 // An upper bound of the three magnitudes that is NaN when any of them is (a three-operand maximum drops
@@ -209,7 +216,7 @@ PT_DEV uint32_t rng_bounded(Rng& r) {
 	constexpr uint32_t threshold = (0u - BOUND) % BOUND;
 	for(;;) {
 		uint32_t v = rng_next(r);
-		if(v >= threshold) return v % BOUND;
+		if(PT_OFTEN2(v >= threshold)) return v % BOUND;
 	}
 }
 
@@ -594,7 +601,7 @@ PT_DEV float intersect(const GeoRef& g, v4f p0, V3 rp, V3 rd, V3& pos, V3& nrm, 
 	v4f p3 = g.plane(G_DIM);
 	int tf = __float_as_int(p3.w);
 	int type = tf & 0xff;
-	if(type > PT_GEOM_CONE) return -1;
+	if(PT_RARE2(type > PT_GEOM_CONE)) return -1;
 	switch(kind_of(type, (tf >> 8) & FLAG_ROTATED, (tf >> 8) & FLAG_EVEN)) {
 		case KIND_SPHERE: return intersect_kind<KIND_SPHERE>(g, p0, p3, rp, rd, pos, nrm);
 		case KIND_BOX: return intersect_kind<KIND_BOX>(g, p0, p3, rp, rd, pos, nrm, inv);
@@ -1001,7 +1008,7 @@ PT_MARK("chunk_intersected");
 		}
 		if(ordinal >= (int)sh.ncell[owner]) ordinal = -1;           // a leftover of an earlier segment; any true match lies before it
 	}
-	if(__ballot(hit && on_bound != 0) != 0) {
+	if(PT_RARE2(__ballot(hit && on_bound != 0) != 0)) {
 		// a point on a cell's lower bound: the interval of admissible coordinates per axis, cut to the entity's range
 		if(hit && on_bound != 0) {
 			int amin[3], amax[3];
@@ -1388,7 +1395,7 @@ PT_DEV bool shade(const Scene& sc, FrameRef fr, int id, const Surface& surf, V3 
 		v4f m0 = surf.m0, m1 = surf.m1;
 		V3 albedo = v3(m0.x, m0.y, m0.z), emit = v3(m1.x, m1.y, m1.z);
 		float refl = m0.w, ior = m1.w;
-		if(!is_zero(emit)) col = col + att * emit;
+		if(PT_RARE2(!is_zero(emit))) col = col + att * emit;
 		if((FEAT & FEAT_GLASS) && ior != 1.0f) {
 			float ratio = fresnel(rd, hn, ior);
 			V3 through = refract_dir(rd, hn, ior);

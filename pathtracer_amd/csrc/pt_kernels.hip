@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIM
 PT_MARK("loop_begin");
 		uint64_t want = __ballot(state == NEED_PIXEL);
 		while(want != 0) {
-			if(pool_pos == kGroup) {
+			if(PT_RARE2(pool_pos == kGroup)) {     // once in 64 hand-outs
 				if(dry) break;
 				// Groups are dealt from kShards counters (group = count * kShards + shard), each on a cache
 				// line of its own, so that fetches do not queue up behind one address; a wave starts at the
@@ -165,7 +165,7 @@ PT_MARK("loop_begin");
 						shard = (shard + 1u) % kShards;
 					}
 					if(g != 0x80000000u && (g & (kAbortPoll - 1u)) == 0u) {
-						if(*job.abort_flag != 0u) {
+						if(PT_RARE2(*job.abort_flag != 0u)) {
 							for(uint32_t k = 0; k < kShards; k++) atomicOr(job.group_counter + k * kShardStride, 0x80000000u);
 							g = 0x80000000u;
 						}
