@@ -1334,7 +1334,7 @@ PT_MARK("verdict_begin");
 				result = (int)(key & 0x7fffffu) + 1;
 				get6(sh.res[lane], hpos, hnrm);
 				walking = false;
-			} else if(recorded == m) {
+			} else if(PT_OFTEN2(recorded == m)) {
 				if(!more) walking = false;   // the ray has left the grid; else the probe stands on the first cell of the next segment
 			} else {
 				// stopped early: resume at the first cell not recorded
