@@ -23,7 +23,7 @@ enum {
 	PT_GEOM_BOX = 1,
 	PT_GEOM_CYLINDER = 2,
 	PT_GEOM_CONE = 3,
-	PT_GEOM_PLANE = 4,    /* accepted by the CPU oracle only; the device path rejects it */
+	PT_GEOM_PLANE = 4,    /* the infinite plane through pos with normal rot * (0,0,1) (code/raycast.cpp:885-889); dim is ignored */
 };
 
 enum {
@@ -98,9 +98,9 @@ typedef struct pt_settings {
 	                                buffer; -1 = full render of every sample */
 	int32_t sample_ranges;       /* a pixel's samples are summed in this many contiguous ranges (range r of n samples is
 	                                [r*n/ranges, (r+1)*n/ranges), each summed in sample order; the range sums are then added
-	                                in range order).  A power of two up to 16, or 0 = chosen from spp_wanted by
-	                                pt_sample_ranges().  The reference adds all samples in one sequence (= 1 range,
-	                                code/raycast.cpp:1263); more ranges only change the rounding of that sum. */
+	                                in range order).  A power of two up to 16, or 0 = chosen from spp_wanted by pt_sample_ranges().  The
+	                                reference adds all samples in one sequence (= 1 range, code/raycast.cpp:1263); more
+	                                ranges only change the rounding of that sum. */
 } pt_settings;
 
 typedef struct pt_progress {
@@ -109,7 +109,8 @@ typedef struct pt_progress {
 	float fraction;              /* 0..1, share of the frame's work groups (8x8 tile x sample range) handed out so far;
 	                                after an abort: the share of pixels that were finished */
 	double seconds;              /* since pt_render_start, the reference's processTime (code/app.cpp:1440) */
-	uint64_t paths_done;         /* camera samples of the pixels finished so far (exact once done, aborted or not) */
+	uint64_t paths_done;         /* while the frame is in flight: an estimate, the frame's camera samples times `fraction`;
+	                                once done (aborted or not): the exact count of the finished pixels' camera samples */
 } pt_progress;
 
 typedef struct pt_stats {
@@ -206,6 +207,12 @@ int pt_get_stats(const pt_ctx* ctx, pt_stats* stats);
  * the prepared scene.
  */
 int pt_debug_primary(pt_ctx* ctx, int32_t* hit_id, uint64_t* cell_hash);
+/* Metrics the reference's statistics panel lacks and a headless run wants (the harness's bounce histogram): histogram[k],
+ * 1 <= k < bins, = camera samples of this context's partition whose path casts k rays in the frame the prepared scene
+ * renders (k <= max_bounces; the last bin also takes every longer path; 2 <= bins <= 65).  The bins add up to
+ * pt_stats.paths, and k * histogram[k] to pt_stats.rays.  A pass of its own over every sample with the tracer's own
+ * device functions and random streams (on a grid scene it takes several times a frame's time). */
+int pt_cast_histogram(pt_ctx* ctx, uint64_t* histogram, int bins);
 /* Diagnostic builds of the library only (-DPT_COOP_STATS / -DPT_COOP_TIMING): copies out and clears 16
  * event or cycle counters of the trace kernel; returns 16, or 0 in a normal build (nothing written).
  * No counterpart in the reference. */
@@ -230,16 +237,21 @@ int pt_cast_rays(pt_ctx* ctx, const float* origins, const float* dirs, int n,
 int pt_pick_rays(pt_ctx* ctx, const float* origins, const float* dirs, int n,
                  int32_t* hit_id, float* hit_pos, float* hit_normal);
 
-/* pt_cast_rays for callers that cannot allocate device memory (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments, same
- * results; the rays and their results are staged in an array that is part of the library's device image
- * (208 KiB per GPU, held until the process ends) instead of a buffer the context allocates and grows, so the
- * call contains no hipMalloc / hipFree.  At most PT_NOALLOC_MAX_RAYS rays a call (PT_ERR_LIMIT beyond).  All
- * contexts on one GPU share that GPU's array: calls that overlap in time on one GPU race; calls one after
- * another need nothing cleared in between (a call reads back only words it wrote itself). */
+/* pt_cast_rays for callers that cannot allocate device memory (tight serving loops, harnesses that forbid hipMalloc,
+ * processes that have handed all free memory to something else).  It has no counterpart in the reference.  Same
+ * arguments, same results; the rays and their results are staged in an array that is part of the library's device
+ * image (208 KiB per GPU, held until the process ends) instead of a buffer the context allocates and grows, so the
+ * call contains no hipMalloc / hipFree.  At most PT_NOALLOC_MAX_RAYS rays a call (PT_ERR_LIMIT beyond).  All contexts
+ * on one GPU share that GPU's array: the library serialises their calls with one lock per GPU, and refuses the call
+ * with PT_ERR_BUSY while the context's own asynchronous render is active; calls one after another need nothing
+ * cleared in between (a call reads back only words it wrote itself).  The call is synchronous: it copies from and to
+ * the caller's (pageable) host memory and waits for the device, so it cannot be recorded into a HIP graph. */
 enum { PT_NOALLOC_MAX_RAYS = 4096 };
 int pt_cast_rays_noalloc(pt_ctx* ctx, const float* origins, const float* dirs, int n,
                          int32_t* hit_id, float* hit_pos, float* hit_normal);
+/* For tests: free and total memory of the context's device (hipMemGetInfo) and the capacity of the context's own
+ * growing scratch buffer, so that a test can assert that a call allocated nothing. */
+int pt_debug_device_memory(pt_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes, uint64_t* scratch_capacity);
 
 /* Arithmetic probes, for tests.  The device computes the reference's divisions and square roots
  * (normVec3 code/rt_math.cpp:2166-2168, lenVec3 :2130-2164, Vec3 / float :2093) with shorter instruction

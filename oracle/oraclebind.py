@@ -107,6 +107,7 @@ def load_oracle():
     _sig(lib, "pto_path_count", C.c_uint64, VP)
     _sig(lib, "pto_counters", None, VP, U64P)
     _sig(lib, "pto_counters_reset", None, VP)
+    _sig(lib, "pto_cast_histogram", None, VP, U64P, C.c_int)
     _sig(lib, "pto_srgb8", None, C.c_int, FP, U8P)
     _sig(lib, "pto_srgb8_check", C.c_uint64, FP, C.c_uint32, C.c_uint64)
     return lib
@@ -193,6 +194,11 @@ class OracleScene:
         c = np.zeros(16, np.uint64)
         self.lib.pto_counters(self.h, c.ctypes.data_as(U64P))
         return dict(zip(COUNTER_NAMES, (int(v) for v in c)))
+
+    def cast_histogram(self, bins=65):
+        h = np.zeros(bins, np.uint64)
+        self.lib.pto_cast_histogram(self.h, h.ctypes.data_as(U64P), bins)
+        return h
 
     def sample_radiance(self, x, y, cap=8192):
         out = np.zeros((cap, 3), np.float32)

@@ -159,8 +159,10 @@ typedef struct { v3i coord_min, coord_max, bmin, bmax, cell_count, cell_size; } 
 /* Per-ray traversal state: the "Grid Traversal" half of SpatialGrid (code/raycast.cpp:304-317). */
 typedef struct { v3i coord, step; v3 tmax, tdelta; int outside; v3 box_min, box_max; } walk_t;
 
+#define PTO_HIST_BINS 65
 typedef struct { uint64_t casts, dda_steps, bsphere_tests, isect[5], rotated_box, uneven_sphere,
-                 shade_opaque, shade_oren, shade_glass, paths, lens, emit; } counters_t;
+                 shade_opaque, shade_oren, shade_glass, paths, lens, emit;
+                 uint64_t path_casts[PTO_HIST_BINS]; /* [k]: camera samples whose path cast k rays (the last bin takes the rest) */ } counters_t;
 
 typedef struct pto_scene {
 	pt_world win; pt_settings st;
@@ -175,6 +177,11 @@ typedef struct pto_scene {
 	int sample_count; v2* samples; int* offsets; int grid_w;
 	grid_t grid; int cells; uint32_t* cell_start; uint32_t* cell_items;
 	counters_t cnt;
+	/* The reference keeps the traverse-init's `outside` flag in the tile job's copy of the grid and only rewrites it for rays
+	 * that start outside the grid's box (code/raycast.cpp:619-638): a ray that starts inside inherits the flag of the last ray
+	 * that started outside.  Under PT_SEED_PER_JOB (the reference's structure) the oracle does the same, from `false` at the
+	 * start of every job; under PT_SEED_PER_SAMPLE, whose paths are independent by definition, every ray starts from `false`. */
+	int sticky_outside, outside_state;
 } pto_scene;
 
 /* ---- intersectors: code/raycast.cpp:390-585, code/rt_math.cpp:2343-2373 -------------------- */
@@ -851,8 +858,9 @@ static int cast_all(pto_scene* s, v3 rp, v3 rd, int outside, v3* ipos, v3* inrm)
 static int cast_grid(pto_scene* s, v3 rp, v3 rd, v3* ipos, v3* inrm, uint64_t* hash) {
 	const grid_t* g = &s->grid;
 	walk_t w;
-	w.outside = 0;
+	w.outside = s->sticky_outside ? s->outside_state : 0;
 	walk_init(g, &w, rp, rd);
+	if(s->sticky_outside) s->outside_state = w.outside;
 	int id = 0;
 	float min_d = FLT_MAX;
 	if(w.outside) {
@@ -895,8 +903,9 @@ static int cast(pto_scene* s, v3 rp, v3 rd, v3* ipos, v3* inrm, uint64_t* hash) 
 	s->cnt.casts++;
 	if(s->n < s->st.brute_force_below) {
 		walk_t w;
-		w.outside = 0;
+		w.outside = s->sticky_outside ? s->outside_state : 0;
 		walk_init(&s->grid, &w, rp, rd);
+		if(s->sticky_outside) s->outside_state = w.outside;
 		return cast_all(s, rp, rd, w.outside, ipos, inrm);
 	}
 	return cast_grid(s, rp, rd, ipos, inrm, hash);
@@ -949,10 +958,12 @@ static v3 trace_sample(pto_scene* s, const frame_t* f, v3 cam_pixel_pos, v2 smp,
 
 	v3 color = V3(0, 0, 0);
 	v3 att = V3(1, 1, 1);
+	int path_casts = 0;
 	for(int ray = 0; ray < s->st.max_bounces; ray++) {
 		v3 ip = V3(0, 0, 0), in = V3(0, 0, 0);
 		uint64_t h = HASH_INIT;
 		int id = cast(s, ray_pos, ray_dir, &ip, &in, &h);
+		path_casts++;
 		if(ray == 0) {
 			if(first_hit) *first_hit = id;
 			if(first_hash) *first_hash = (s->n < s->st.brute_force_below) ? 0 : h;
@@ -1028,6 +1039,7 @@ static v3 trace_sample(pto_scene* s, const frame_t* f, v3 cam_pixel_pos, v2 smp,
 			break;
 		}
 	}
+	s->cnt.path_casts[path_casts < PTO_HIST_BINS ? path_casts : PTO_HIST_BINS - 1]++;
 	return color;
 }
 
@@ -1054,11 +1066,14 @@ static int sample_ranges(const pt_settings* st) {
 	return ranges;
 }
 
+/* First sample of range r of a pixel that has `count` samples, cut into `ranges` even ranges. */
+static inline int range_start(int count, int range, int ranges) { return (int)(((long long)range * count) / ranges); }
+
 /* One pixel, all its samples. rng is the job's generator under PT_SEED_PER_JOB and scratch
  * otherwise. per_sample (optional) receives the unclamped radiance of every sample.
  * Under PT_SEED_PER_JOB the clamped sample colours are added in one sequence, as the reference
- * does; under PT_SEED_PER_SAMPLE they are added range by range (range r of count samples is
- * [r*count/ranges, (r+1)*count/ranges)) and the range sums are then added in range order. */
+ * does; under PT_SEED_PER_SAMPLE they are added range by range (range_start above) and the range
+ * sums are then added in range order. */
 static v3 trace_pixel(pto_scene* s, const frame_t* f, int x, int y, int policy, pcg32* rng, float* per_sample,
                       int* first_hit, uint64_t* first_hash) {
 	v3 cpp = pixel_pos(s, f, x, y);
@@ -1081,7 +1096,7 @@ static v3 trace_pixel(pto_scene* s, const frame_t* f, int x, int y, int policy, 
 	const int ranges = policy == PT_SEED_PER_JOB ? 1 : sample_ranges(&s->st);
 	for(int range = 0; range < ranges; range++) {
 		v3 part = V3(0, 0, 0);
-		for(int si = range * count / ranges; si < (range + 1) * count / ranges; si++) {
+		for(int si = range_start(count, range, ranges); si < range_start(count, range + 1, ranges); si++) {
 			pcg32 sr;
 			pcg32* r = rng;
 			if(policy != PT_SEED_PER_JOB) { sample_stream(s, x, y, si, 0, &sr); r = &sr; }
@@ -1135,6 +1150,8 @@ static int make_jobs(int width, int height, int* xywh, int cap) {
 static void run_job(pto_scene* s, const frame_t* f, const int* job, int job_index, int policy, uint64_t seed_base, float* rgb) {
 	pcg32 rng;
 	pcg_seed(&rng, 0, seed_base + (uint64_t)job_index);
+	s->sticky_outside = policy == PT_SEED_PER_JOB;
+	s->outside_state = 0;
 	int w = s->st.width, h = s->st.height;
 	int pixels = job[2] * job[3];
 	for(int pi = 0; pi < pixels; pi++) {
@@ -1145,6 +1162,7 @@ static void run_job(pto_scene* s, const frame_t* f, const int* job, int job_inde
 		float* o = rgb + 3 * ((size_t)y * w + x);
 		o[0] = c.x; o[1] = c.y; o[2] = c.z;
 	}
+	s->sticky_outside = 0;
 }
 
 /* ---- exported API ---------------------------------------------------------------------------- */
@@ -1442,7 +1460,13 @@ uint64_t pto_path_count(const pto_scene* s) {
 /* Event counters accumulated by every render since creation (16 values):
  * casts, dda_steps, bsphere_tests, isect[sphere,box,cylinder,cone,plane], rotated_box, uneven_sphere,
  * shade_opaque, shade_oren, shade_glass, paths, lens, emit. */
-void pto_counters(const pto_scene* s, uint64_t* out) { memcpy(out, &s->cnt, sizeof(counters_t)); }
+void pto_counters(const pto_scene* s, uint64_t* out) { memcpy(out, &s->cnt, 16 * sizeof(uint64_t)); }
+/* out[k], k < bins: camera samples traced since creation (or the last reset) whose path cast k rays; the last bin
+ * also takes every longer path. */
+void pto_cast_histogram(const pto_scene* s, uint64_t* out, int bins) {
+	for(int k = 0; k < bins; k++) out[k] = 0;
+	for(int k = 0; k < PTO_HIST_BINS; k++) if(bins > 0) out[k < bins ? k : bins - 1] += s->cnt.path_casts[k];
+}
 void pto_counters_reset(pto_scene* s) { memset(&s->cnt, 0, sizeof(counters_t)); }
 
 /* Screenshot encoding: code/app.cpp:1541-1547, code/rt_math.cpp:351-353,3634-3640. */

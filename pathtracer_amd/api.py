@@ -177,6 +177,8 @@ def load_core():
     lib.pt_image_free.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.pt_pick_rays.argtypes = lib.pt_cast_rays.argtypes
     lib.pt_cast_rays_noalloc.argtypes = lib.pt_cast_rays.argtypes
+    lib.pt_cast_histogram.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+    lib.pt_debug_device_memory.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.pt_render_snapshot.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
     lib.pt_present_srgb8.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
     lib.pt_debug_srgb8.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_uint8)]
@@ -360,6 +362,12 @@ class Renderer:
         bad = C.c_uint64(0)
         self._check(self.lib.pt_debug_arith_sweep(self.ctx, op, first_bits, count, C.byref(bad)), "pt_debug_arith_sweep")
         return bad.value
+
+    def cast_histogram(self, bins=65):
+        """hist[k] = camera samples whose path casts k rays (pt_cast_histogram)."""
+        hist = np.zeros(bins, np.uint64)
+        self._check(self.lib.pt_cast_histogram(self.ctx, u64ptr(hist), bins), "pt_cast_histogram")
+        return hist
 
     def present_srgb8(self):
         s = self.settings

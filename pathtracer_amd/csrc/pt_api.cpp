@@ -25,6 +25,11 @@ namespace {
 
 std::string g_create_error;
 
+// The static staging array of pt_cast_rays_noalloc exists once per GPU and is shared by every context on it: one lock
+// per device ordinal serialises the calls that use it.
+constexpr int kMaxDevices = 64;
+std::mutex g_static_scratch_mu[kMaxDevices];
+
 struct DevBuf {
 	void* p = nullptr;
 	size_t cap = 0;
@@ -58,7 +63,7 @@ struct pt_ctx {
 	std::atomic<bool> prepared{ false };
 
 	// device-resident scene
-	DevBuf geo, cell_start, cell_items, cell_entries, obj_range, partial, fracs, bbox, grid_cursor, grid_sums, tile_cost, tile_order, dirs, disc, samples, offsets, frame_dev, fb, accum, counter, stats_dev, scratch;
+	DevBuf geo, cell_start, cell_items, cell_entries, obj_range, plane_ids, partial, fracs, bbox, grid_cursor, grid_sums, tile_cost, tile_order, dirs, disc, samples, offsets, frame_dev, fb, accum, counter, stats_dev, scratch;
 	DevBuf thresholds;                   // the screenshot encoder's table
 	bool thresholds_ready = false;
 	void* dl_host = nullptr;             // pinned staging image of downloads into pageable memory
@@ -67,7 +72,7 @@ struct pt_ctx {
 	void* snap_host = nullptr;           // pinned landing area of snapshots: two halves that take turns (poll thread only)
 	hipEvent_t snap_event[2] = { nullptr, nullptr };
 	ptl::TraceCaps caps{};               // compute units and resident workgroups per unit, of this context's device
-	hipStream_t last_stream = nullptr;   // the stream the latest pt_trace went to
+	std::vector<hipStream_t> used_streams;   // caller streams pt_trace launched on since the last wait (the context's own stream is always waited for)
 	void* static_scratch = nullptr;      // this device's copy of the library's static staging array (pt_cast_rays_noalloc)
 	size_t static_scratch_bytes = 0;
 	uint32_t* abort_flag = nullptr;      // host-pinned, read by the trace kernel
@@ -158,8 +163,8 @@ int validate(pt_ctx* c, const pt_world* w, const pt_object* objs, int n, const p
 	if(s->frame_index < -1) return fail(c, PT_ERR_ARG, "frame_index must be >= -1");
 	if(pt_sample_ranges(s) < 0) return fail(c, PT_ERR_ARG, "sample_ranges must be 0 or a power of two up to 16, not %d", s->sample_ranges);
 	for(int i = 0; i < n; i++) {
-		if(objs[i].type < PT_GEOM_SPHERE || objs[i].type > PT_GEOM_CONE)
-			return fail(c, PT_ERR_ARG, "object %d: geometry type %d is not supported on the device (sphere, box, cylinder, cone)", i, objs[i].type);
+		if(objs[i].type < PT_GEOM_SPHERE || objs[i].type > PT_GEOM_PLANE)
+			return fail(c, PT_ERR_ARG, "object %d: unknown geometry type %d (sphere, box, cylinder, cone, plane)", i, objs[i].type);
 	}
 	return PT_OK;
 }
@@ -210,7 +215,10 @@ int grid_build_device(pt_ctx* c, const std::vector<float>& rec, int n, const pt:
 	*done = false;
 	const size_t cells = (size_t)gd.cells();
 	std::vector<float> box((size_t)n * 4, 0.0f);
-	for(int i = 0; i < n; i++) memcpy(box.data() + (size_t)i * 4, rec.data() + (size_t)i * PT_F_STRIDE + PT_F_BBOX, 12);
+	for(int i = 0; i < n; i++) {
+		memcpy(box.data() + (size_t)i * 4, rec.data() + (size_t)i * PT_F_STRIDE + PT_F_BBOX, 12);
+		box[(size_t)i * 4 + 3] = pt::filter_radius(rec.data() + (size_t)i * PT_F_STRIDE);
+	}
 	int rc;
 	if((rc = upload(c, c->bbox, box.data(), box.size() * 4))) return rc;
 	PT_HIP(c, c->cell_start.reserve((cells + 1) * 4));
@@ -291,14 +299,17 @@ int prepare(pt_ctx* c) {
 	// one 128-byte record of eight float4 per entity (layout documented in pt_device.h)
 	const size_t np = (size_t)(n > 0 ? n : 1);
 	std::vector<float> geo(np * ptl::REC_STRIDE * 4, 0.0f);
-	int features = 0;          // what the entities need of a kernel variant: 1 unit-space kinds, 2 glass, 4 roughness (FEAT_* in pt_device.h)
+	int features = 0;          // what the entities need of a kernel variant: 1 unit-space kinds, 2 glass, 4 roughness, 8 planes (FEAT_* in pt_device.h)
+	std::vector<uint32_t> plane_ids;
 	for(int i = 0; i < n; i++) {
 		const float* r = rec.data() + (size_t)i * PT_F_STRIDE;
 		int32_t type, flags;
 		memcpy(&type, r + PT_F_TYPE, 4);
 		memcpy(&flags, r + PT_F_FLAGS, 4);
 		const bool direct = (type == PT_GEOM_SPHERE && (flags & 2)) || (type == PT_GEOM_BOX && !(flags & 1));
-		if(!direct) features |= 1;
+		const bool plane = type == PT_GEOM_PLANE;
+		if(plane) { features |= 8; plane_ids.push_back((uint32_t)i); }
+		else if(!direct) features |= 1;
 		if(r[PT_F_IOR] != 1.0f) features |= 2;
 		if(r[PT_F_ROUGH] != 0.0f) features |= 4;
 		int32_t tf = type | (flags << 8);
@@ -322,12 +333,21 @@ int prepare(pt_ctx* c) {
 			}
 			lo[3] = 0; hi[3] = 0;
 		}
+		if(plane) {
+			// a plane reads no inverse rotation: the slot holds its normal, rot * (0, 0, 1), which the reference works out at every test
+			float* nrm = slot(ptl::REC_ROTINV);
+			pt::plane_normal(r, nrm);
+			nrm[3] = 0;
+		}
 		float* m0 = slot(ptl::REC_COLOR); m0[0] = r[PT_F_COLOR]; m0[1] = r[PT_F_COLOR + 1]; m0[2] = r[PT_F_COLOR + 2]; m0[3] = r[PT_F_REFL];
 		float* m1 = slot(ptl::REC_EMIT); m1[0] = r[PT_F_EMIT]; m1[1] = r[PT_F_EMIT + 1]; m1[2] = r[PT_F_EMIT + 2]; m1[3] = r[PT_F_IOR];
 	}
 
 	int rc;
 	if((rc = upload(c, c->geo, geo.data(), geo.size() * 4))) return rc;
+	if(plane_ids.empty()) plane_ids.push_back(0u);       // never read: the count below says so
+	if((rc = upload(c, c->plane_ids, plane_ids.data(), plane_ids.size() * 4))) return rc;
+	const int n_planes = (features & 8) ? (int)plane_ids.size() : 0;
 	bool coop = false;
 	size_t item_total = 0;
 	c->grid_built_on_device = false;
@@ -364,7 +384,7 @@ int prepare(pt_ctx* c) {
 					if(at[a] < ((hi >> (10 * a)) & 1023u)) tag |= 1u << (4 + 2 * a);
 				}
 				uint32_t w[4];
-				ptl::pack_entry(r[PT_F_POS], r[PT_F_POS + 1], r[PT_F_POS + 2], r[PT_F_BRADIUS], tag, id, w);
+				ptl::pack_entry(r[PT_F_POS], r[PT_F_POS + 1], r[PT_F_POS + 2], pt::filter_radius(r), tag, id, w);
 				memcpy(entries.data() + (size_t)k * 4, w, 16);
 			}
 		}
@@ -425,6 +445,8 @@ int prepare(pt_ctx* c) {
 	j.scene.disc = c->disc.as<float2>();
 	j.scene.samples = c->samples.as<float2>();
 	j.scene.offsets = c->offsets.as<int32_t>();
+	j.scene.plane_ids = c->plane_ids.as<uint32_t>();
+	j.scene.n_planes = n_planes;
 	j.scene.n = n;
 	j.scene.brute = n < s.brute_force_below ? 1 : 0;
 	j.scene.grid = grid_dev(gd);
@@ -528,7 +550,7 @@ int trace(pt_ctx* c, float* d_rgb, hipStream_t stream, bool sync, bool write_thr
 	ptl::TraceJob job = c->job;
 	if(d_rgb) job.fb = d_rgb;
 	hipStream_t s = stream ? stream : c->stream;
-	c->last_stream = s;
+	if(s != c->stream && std::find(c->used_streams.begin(), c->used_streams.end(), s) == c->used_streams.end()) c->used_streams.push_back(s);
 	if(++c->serial >= 0x80000000u) c->serial = 1;
 	job.serial = c->serial | (write_through ? 0x80000000u : 0u);
 	job.group_counter = c->counter.as<uint32_t>() + (size_t)c->counter_set * 1024;
@@ -588,29 +610,32 @@ int collect(pt_ctx* c) {
 		for(hipEvent_t e : p) c->event_pool.push_back(e);
 	}
 	if(!pend.empty()) {
-		c->kernel_ms_sum = sum;
-		c->kernel_launches = (int)pend.size();
-		c->stats.trace_ms = (float)(whole / pend.size());
-		c->stats.dominant_kernel_ms = (float)(sum / pend.size());
-		c->stats.trace_ms_min = lo; c->stats.trace_ms_max = hi; c->stats.trace_launches = (int)pend.size();
 		// on the library's stream: the caller has waited for every stream the launches went to
 		uint64_t rays = 0;
 		PT_HIP(c, hipMemcpyAsync(&rays, c->stats_dev.p, sizeof rays, hipMemcpyDeviceToHost, c->stream));
 		PT_HIP(c, hipMemsetAsync(c->stats_dev.p, 0, 256, c->stream));
 		PT_HIP(c, hipStreamSynchronize(c->stream));
+		std::lock_guard<std::mutex> l(c->mu);             // pt_get_stats may be reading from another thread
+		c->kernel_ms_sum = sum;
+		c->kernel_launches = (int)pend.size();
+		c->stats.trace_ms = (float)(whole / pend.size());
+		c->stats.dominant_kernel_ms = (float)(sum / pend.size());
+		c->stats.trace_ms_min = lo; c->stats.trace_ms_max = hi; c->stats.trace_launches = (int)pend.size();
 		c->stats.rays = rays / (uint64_t)(c->launches_since_readout > 0 ? c->launches_since_readout : 1);   // the device counter adds up every launch, timed or not
 		c->launches_since_readout = 0;
 	}
 	return PT_OK;
 }
 
-// Waits for every stream recent launches went to.
+// Waits for every stream launches went to since the last wait: the context's own and each distinct caller stream (a
+// caller that alternates between two streams of its own has work pending on both).
 int wait_launches(pt_ctx* c) {
 	PT_HIP(c, hipStreamSynchronize(c->stream));
-	if(c->last_stream && c->last_stream != c->stream) {
+	for(hipStream_t s : c->used_streams) {
 		// a caller's stream that no longer exists has nothing left to wait for
-		if(hipStreamSynchronize(c->last_stream) != hipSuccess) (void)hipGetLastError();
+		if(hipStreamSynchronize(s) != hipSuccess) (void)hipGetLastError();
 	}
+	c->used_streams.clear();
 	return PT_OK;
 }
 
@@ -818,7 +843,7 @@ void pt_destroy(pt_ctx* c) {
 	if(c->active.load()) { *c->abort_flag = 1; join_worker(c); }
 	(void)hipSetDevice(c->device);
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
-	for(DevBuf* b : { &c->geo, &c->cell_start, &c->cell_items, &c->cell_entries, &c->obj_range, &c->partial, &c->fracs, &c->bbox, &c->grid_cursor, &c->grid_sums, &c->tile_cost, &c->tile_order, &c->dirs, &c->disc, &c->samples, &c->offsets, &c->frame_dev, &c->fb, &c->accum, &c->counter, &c->stats_dev, &c->scratch, &c->thresholds }) b->release();
+	for(DevBuf* b : { &c->geo, &c->cell_start, &c->cell_items, &c->cell_entries, &c->obj_range, &c->plane_ids, &c->partial, &c->fracs, &c->bbox, &c->grid_cursor, &c->grid_sums, &c->tile_cost, &c->tile_order, &c->dirs, &c->disc, &c->samples, &c->offsets, &c->frame_dev, &c->fb, &c->accum, &c->counter, &c->stats_dev, &c->scratch, &c->thresholds }) b->release();
 	if(c->snap_host) (void)hipHostFree(c->snap_host);
 	for(auto& p : c->pending) for(hipEvent_t e : p) (void)hipEventDestroy(e);
 	for(hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
@@ -929,6 +954,8 @@ int pt_download(pt_ctx* c, float* rgb) {
 
 int pt_get_stats(const pt_ctx* c, pt_stats* out) {
 	if(!c || !out) return PT_ERR_ARG;
+	// the worker of an asynchronous render folds its launch's events into the statistics under the same lock
+	std::lock_guard<std::mutex> l(const_cast<pt_ctx*>(c)->mu);
 	*out = c->stats;
 	return PT_OK;
 }
@@ -1137,8 +1164,10 @@ int group_part(pt_group* g, int p, size_t stride_floats, bool* gathered) {
 		rc = download(c, g->user_rgb);
 	} else {
 		float* to = g->gathered.as<float>() + (size_t)p * stride_floats;
-		PT_HIP(c, hipMemcpyPeerAsync(to, root->device, c->fb.p, c->device, c->fb_floats * 4, c->stream));
-		PT_HIP(c, hipStreamSynchronize(c->stream));
+		if(c->fb_floats > 0) {                 // a partition of a tiny image may own no tile at all
+			PT_HIP(c, hipMemcpyPeerAsync(to, root->device, c->fb.p, c->device, c->fb_floats * 4, c->stream));
+			PT_HIP(c, hipStreamSynchronize(c->stream));
+		}
 		*gathered = true;
 	}
 	if(rc == PT_OK) { g->done_pixels.fetch_add(pixels); g->done_paths.fetch_add(paths); }
@@ -1369,8 +1398,25 @@ int pt_debug_primary(pt_ctx* c, int32_t* hit_id, uint64_t* cell_hash) {
 	return PT_OK;
 }
 
+int pt_cast_histogram(pt_ctx* c, uint64_t* histogram, int bins) {
+	if(!c) return PT_ERR_ARG;
+	if(!histogram || bins < 2 || bins > 65) return fail(c, PT_ERR_ARG, "pt_cast_histogram: 2..65 bins");
+	if(c->active.load() && !c->done.load()) return fail(c, PT_ERR_BUSY, "a render is active");
+	if(!c->prepared) return fail(c, PT_ERR_STATE, "pt_cast_histogram before pt_prepare");
+	PT_HIP(c, hipSetDevice(c->device));
+	int rc = wait_launches(c);
+	if(rc) return rc;
+	PT_HIP(c, c->scratch.reserve(65 * 8));
+	PT_HIP(c, hipMemsetAsync(c->scratch.p, 0, 65 * 8, c->stream));
+	PT_HIP(c, ptl::launch_cast_histogram(c->job, c->fb_floats / 3, c->scratch.as<unsigned long long>(), bins, c->stream));
+	PT_HIP(c, hipMemcpyAsync(histogram, c->scratch.p, (size_t)bins * 8, hipMemcpyDeviceToHost, c->stream));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	return PT_OK;
+}
+
 static int cast_rays(pt_ctx* c, int mode, const float* origins, const float* dirs, int n, int32_t* hit_id, float* hit_pos, float* hit_nrm) {
 	if(!c) return PT_ERR_ARG;
+	if(c->active.load() && !c->done.load()) return fail(c, PT_ERR_BUSY, "a render is active");
 	if(!c->prepared) return fail(c, PT_ERR_STATE, "ray query before pt_prepare");
 	if(n < 0 || (n > 0 && (!origins || !dirs || !hit_id))) return fail(c, PT_ERR_ARG, "null argument");
 	if(n == 0) return PT_OK;
@@ -1396,6 +1442,7 @@ int pt_cast_rays(pt_ctx* c, const float* origins, const float* dirs, int n, int3
 
 int pt_cast_rays_noalloc(pt_ctx* c, const float* origins, const float* dirs, int n, int32_t* hit_id, float* hit_pos, float* hit_nrm) {
 	if(!c) return PT_ERR_ARG;
+	if(c->active.load() && !c->done.load()) return fail(c, PT_ERR_BUSY, "a render is active");
 	if(!c->prepared) return fail(c, PT_ERR_STATE, "ray query before pt_prepare");
 	if(n < 0 || (n > 0 && (!origins || !dirs || !hit_id))) return fail(c, PT_ERR_ARG, "null argument");
 	if(n > PT_NOALLOC_MAX_RAYS) return fail(c, PT_ERR_LIMIT, "pt_cast_rays_noalloc takes at most %d rays a call, not %d (pt_cast_rays has no limit)", PT_NOALLOC_MAX_RAYS, n);
@@ -1403,6 +1450,8 @@ int pt_cast_rays_noalloc(pt_ctx* c, const float* origins, const float* dirs, int
 	static_assert(PT_NOALLOC_MAX_RAYS == ptl::kStaticRays, "the header's limit is the staging array's");
 	if(!c->static_scratch || c->static_scratch_bytes < (size_t)PT_NOALLOC_MAX_RAYS * 52) return fail(c, PT_ERR_STATE, "the static staging area is missing");
 	PT_HIP(c, hipSetDevice(c->device));
+	// every context on this GPU stages in the same array: one call at a time per device
+	std::lock_guard<std::mutex> staging(g_static_scratch_mu[c->device % kMaxDevices]);
 	// fixed places in the device's static array, whatever n is; every word a call reads back it has written itself
 	const size_t v = (size_t)n * 12, span = (size_t)PT_NOALLOC_MAX_RAYS * 12;
 	char* base = (char*)c->static_scratch;
@@ -1420,6 +1469,17 @@ int pt_cast_rays_noalloc(pt_ctx* c, const float* origins, const float* dirs, int
 
 int pt_pick_rays(pt_ctx* c, const float* origins, const float* dirs, int n, int32_t* hit_id, float* hit_pos, float* hit_nrm) {
 	return cast_rays(c, 1, origins, dirs, n, hit_id, hit_pos, hit_nrm);
+}
+
+int pt_debug_device_memory(pt_ctx* c, uint64_t* free_bytes, uint64_t* total_bytes, uint64_t* scratch_capacity) {
+	if(!c) return PT_ERR_ARG;
+	PT_HIP(c, hipSetDevice(c->device));
+	size_t f = 0, t = 0;
+	PT_HIP(c, hipMemGetInfo(&f, &t));
+	if(free_bytes) *free_bytes = f;
+	if(total_bytes) *total_bytes = t;
+	if(scratch_capacity) *scratch_capacity = c->scratch.cap;
+	return PT_OK;
 }
 
 int pt_debug_arith(pt_ctx* c, int op, const float* a, const float* b, int n, float* out) {

@@ -34,10 +34,10 @@ typedef const PT_CONST ptl::FrameDev* FrameRef;
 struct Scene {
 	cf4 geo, dirs;
 	cf2 disc, samples;
-	cu32 cell_start, cell_items, obj_range;
+	cu32 cell_start, cell_items, obj_range, plane_ids;
 	cf4 entries;                 // per cell-list entry: bounding sphere, listed-in-neighbour mask, kind, id (ptl::pack_entry)
 	ci32 offsets;
-	int n, brute;
+	int n, brute, n_planes;
 	Grid grid;
 };
 __device__ __forceinline__ Scene scene_view(const ptl::SceneDev& d) {
@@ -46,7 +46,8 @@ __device__ __forceinline__ Scene scene_view(const ptl::SceneDev& d) {
 	s.disc = (cf2)d.disc; s.samples = (cf2)d.samples;
 	s.cell_start = (cu32)d.cell_start; s.cell_items = (cu32)d.cell_items; s.obj_range = (cu32)d.obj_range; s.entries = (cf4)d.cell_entries;
 	s.offsets = (ci32)d.offsets;
-	s.n = d.n; s.brute = d.brute; s.grid = d.grid;
+	s.plane_ids = (cu32)d.plane_ids;
+	s.n = d.n; s.brute = d.brute; s.n_planes = d.n_planes; s.grid = d.grid;
 	return s;
 }
 PT_DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -386,6 +387,19 @@ PT_DEV float hit_cone(V3 p, V3 d, V3& pos, V3& nrm) {
 	return distance;
 }
 
+// linePlaneIntersection (code/rt_math.cpp:2343-2359): the plane through pp with normal pn, either side.
+PT_DEV float hit_plane(V3 lp, V3 ld, V3 pp, V3 pn, V3& pos, V3& nrm) {
+	const float a = dot(pn, ld);
+	if(a == 0) return -1;
+	const float distance = dot(pn, pp - lp) / a;
+	if(distance >= 0) {
+		pos = lp + ld * distance;
+		nrm = a < 0 ? pn : -pn;
+		return distance;
+	}
+	return -1;
+}
+
 // Entity record loader: one entity = G_SLOTS consecutive float4 (128 bytes, one cache line).
 struct GeoRef {
 	cf4 base; int n; int i;
@@ -418,15 +432,29 @@ PT_DEV void to_world(const GeoRef& g, V3 opos, bool rotated, V3& pos, V3& nrm) {
 	nrm = normalise(nrm);
 }
 
+// What a scene contains, as far as kernel variants care: a variant compiled without a feature leaves out
+// its code and its registers; the host picks the variant from the scene (SceneDev::features).
+enum { FEAT_UNIT_KINDS = 1,     // rotated boxes, ellipsoids, cylinders, cones: the kinds that work in an entity's unit space
+       FEAT_GLASS = 2,          // an entity with a refractive index other than 1
+       FEAT_ROUGH = 4,          // an entity with roughness (Oren-Nayar)
+       FEAT_ALL = 7,            // all of the above: every scene of the path's four primitive kinds
+       FEAT_PLANE = 8,          // an infinite plane (GEOM_TYPE_PLANE): tested by every ray that misses the grid, and listed in the
+                                // cells of the grid its huge bounding box covers
+       FEAT_EVERY = 15 };
+
 // Intersection kinds: the six straight-line variants getIntersection (code/raycast.cpp:813-893)
 // dispatches to.  The wave-cooperative cast bins candidates by kind so that a wavefront runs one
 // variant at a time.
-enum { KIND_SPHERE = 0, KIND_BOX = 1, KIND_BOX_ROTATED = 2, KIND_ELLIPSOID = 3, KIND_CYLINDER = 4, KIND_CONE = 5, KIND_COUNT = 6 };
+enum { KIND_SPHERE = 0, KIND_BOX = 1, KIND_BOX_ROTATED = 2, KIND_ELLIPSOID = 3, KIND_CYLINDER = 4, KIND_CONE = 5, KIND_PLANE = 6, KIND_COUNT = 7 };
 PT_DEV int kind_of(int type, bool rotated, bool even) {
 	if(type == PT_GEOM_SPHERE) return even ? KIND_SPHERE : KIND_ELLIPSOID;
 	if(type == PT_GEOM_BOX) return rotated ? KIND_BOX_ROTATED : KIND_BOX;
+	if(type == PT_GEOM_PLANE) return KIND_PLANE;
 	return type == PT_GEOM_CYLINDER ? KIND_CYLINDER : KIND_CONE;
 }
+// the plane's normal, rot * (0, 0, 1) (code/raycast.cpp:887): worked out by the host with the reference's operations and kept in
+// a slot a plane reads for nothing else
+enum { G_PLANE_NORMAL = ptl::REC_ROTINV };
 
 template <int KIND>
 PT_DEV float intersect_kind(const GeoRef& g, v4f p0, v4f p3, V3 rp, V3 rd, V3& pos, V3& nrm, const V3* inv = nullptr) {
@@ -440,6 +468,9 @@ PT_DEV float intersect_kind(const GeoRef& g, v4f p0, v4f p3, V3 rp, V3 rd, V3& p
 		// corners of an unrotated box (pos -/+ dim / 2), kept by the host in two slots such a box never reads
 		v4f lo = g.plane(G_BOX_LO), hi = g.plane(G_BOX_HI);
 		distance = hit_slabs(rp, rd, v3(lo.x, lo.y, lo.z), v3(hi.x, hi.y, hi.z), pos, nrm, inv);
+	} else if(KIND == KIND_PLANE) {
+		const v4f pn = g.plane(G_PLANE_NORMAL);
+		distance = hit_plane(rp, rd, opos, v3(pn.x, pn.y, pn.z), pos, nrm);
 	} else if(KIND == KIND_BOX_ROTATED) {
 		v4f ri = g.plane(G_ROTINV);
 		V3 lp = rp - opos;
@@ -529,11 +560,12 @@ PT_DEV float hit_round(bool cone, V3 p, V3 d, V3& pos, V3& nrm) {
 // runs exactly the operation sequence of its intersect_kind variant.
 // p1 and p4 are the record's other two early slots, fetched by the caller together with p0 and p3.
 constexpr int KIND_MIXED = KIND_COUNT;
+template <int FEAT>
 PT_DEV float intersect_mixed(int kind, const GeoRef& g, v4f p0, v4f p1, v4f p3, v4f p4, V3 rp, V3 rd, V3& pos, V3& nrm, cu32 range_words, uint32_t& range_lo, uint32_t& range_hi) {
 	const V3 opos = v3(p0.x, p0.y, p0.z);
 	const V3 dim = v3(p3.x, p3.y, p3.z);
 	const bool isbox = kind == KIND_BOX_ROTATED;
-	const bool unit = kind >= KIND_BOX_ROTATED;
+	const bool unit = kind >= KIND_BOX_ROTATED && (!(FEAT & FEAT_PLANE) || kind != KIND_PLANE);
 	const bool turned = isbox || (unit && ((__float_as_int(p3.w) >> 8) & FLAG_ROTATED));
 	V3 a = rp, ld = rd, sinv = v3(1, 1, 1);
 	if(unit) {
@@ -550,7 +582,9 @@ PT_DEV float intersect_mixed(int kind, const GeoRef& g, v4f p0, v4f p1, v4f p3, 
 		ld = normalise(din);
 	}
 	float distance;
-	if(kind == KIND_BOX || isbox) {
+	if((FEAT & FEAT_PLANE) && kind == KIND_PLANE) {
+		distance = hit_plane(rp, rd, opos, v3(p1.x, p1.y, p1.z), pos, nrm);      // p1: G_PLANE_NORMAL
+	} else if(kind == KIND_BOX || isbox) {
 		V3 bmin, bmax;
 		if(isbox) {
 			const V3 half = dim * 0.5f;            // the same floats as dim / 2
@@ -588,20 +622,16 @@ PT_DEV float intersect_mixed(int kind, const GeoRef& g, v4f p0, v4f p1, v4f p3, 
 	return distance;
 }
 
-// What a scene contains, as far as kernel variants care: a variant compiled without a feature leaves out
-// its code and its registers; the host picks the variant from the scene (SceneDev::features).
-enum { FEAT_UNIT_KINDS = 1,     // rotated boxes, ellipsoids, cylinders, cones: the kinds that work in an entity's unit space
-       FEAT_GLASS = 2,          // an entity with a refractive index other than 1
-       FEAT_ROUGH = 4,          // an entity with roughness (Oren-Nayar)
-       FEAT_ALL = 7 };
-
 // getIntersection (code/raycast.cpp:813-893).  p0 = plane G_POS already loaded by the caller.
 template <int FEAT = FEAT_ALL>
 PT_DEV float intersect(const GeoRef& g, v4f p0, V3 rp, V3 rd, V3& pos, V3& nrm, const V3* inv = nullptr) {
 	v4f p3 = g.plane(G_DIM);
 	int tf = __float_as_int(p3.w);
 	int type = tf & 0xff;
-	if(PT_RARE2(type > PT_GEOM_CONE)) return -1;
+	if(PT_RARE2(type > PT_GEOM_CONE)) {
+		if((FEAT & FEAT_PLANE) && type == PT_GEOM_PLANE) return intersect_kind<KIND_PLANE>(g, p0, p3, rp, rd, pos, nrm);
+		return -1;
+	}
 	switch(kind_of(type, (tf >> 8) & FLAG_ROTATED, (tf >> 8) & FLAG_EVEN)) {
 		case KIND_SPHERE: return intersect_kind<KIND_SPHERE>(g, p0, p3, rp, rd, pos, nrm);
 		case KIND_BOX: return intersect_kind<KIND_BOX>(g, p0, p3, rp, rd, pos, nrm, inv);
@@ -723,13 +753,22 @@ template <int FEAT = FEAT_ALL, bool GRID_GATE = true>
 PT_DEV int cast_all(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface& surf) {
 	V3 entry;
 	const V3 inv = recip3(rd);          // for the grid's box and every upright box of the scene
-	if(GRID_GATE && !grid_entry(sc.grid, rp, rd, entry, &inv)) return 0;   // outside: only planes would be tested, and there are none
+	bool outside = false;               // the ray never meets the grid: only planes are tested (code/raycast.cpp:903)
+	if(GRID_GATE && !grid_entry(sc.grid, rp, rd, entry, &inv)) {
+		if(!(FEAT & FEAT_PLANE)) return 0;      // and this scene has none
+		outside = true;
+	}
 	int id = 0;
 	float best = 3.402823466e+38f;
 	for(int i = 0; i < sc.n; i++) {
 		GeoRef g = { sc.geo, sc.n, i };
 		v4f p0 = g.plane(G_POS);
-		if(touches_sphere(rp, rd, v3(p0.x, p0.y, p0.z), p0.w)) {
+		bool plane = false;
+		if(FEAT & FEAT_PLANE) {
+			plane = (__float_as_int(g.plane(G_DIM).w) & 0xff) == PT_GEOM_PLANE;      // wave-uniform
+			if(outside && !plane) continue;
+		}
+		if(plane || touches_sphere(rp, rd, v3(p0.x, p0.y, p0.z), p0.w)) {      // a plane has no bounding sphere (code/raycast.cpp:909)
 			V3 p, q;
 			float distance = intersect<FEAT>(g, p0, rp, rd, p, q, &inv);
 			if(distance > 0 && distance < best) {
@@ -744,13 +783,35 @@ PT_DEV int cast_all(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface& 
 	return id;
 }
 
+// The rays that never meet the grid test the scene's planes, all of them, and the last one hit is the result, whatever its
+// distance, a distance of zero included (code/raycast.cpp:937-955).
+PT_DEV int cast_planes(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm) {
+	int id = 0;
+	for(int k = 0; k < sc.n_planes; k++) {
+		const int oi = (int)sc.plane_ids[k];
+		GeoRef g = { sc.geo, sc.n, oi };
+		const v4f p0 = g.plane(G_POS);
+		V3 p, q;
+		const float distance = intersect_kind<KIND_PLANE>(g, p0, p0, rp, rd, p, q);
+		if(distance != -1) { id = oi + 1; hpos = p; hnrm = q; }
+	}
+	return id;
+}
+
 // castRay (code/raycast.cpp:928-986): walk the grid, accept a hit only inside the current cell,
 // stop at the first cell that produced one.  Items are in ascending id, so on equal distance the
 // lowest id wins, as in the reference.
-template <bool HASH>
+template <bool HASH, int FEAT = FEAT_EVERY>
 PT_DEV int cast_grid(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface& surf, uint64_t& hash) {
 	V3 start;
-	if(!grid_entry(sc.grid, rp, rd, start)) return 0;
+	if(!grid_entry(sc.grid, rp, rd, start)) {
+		int outside_id = 0;
+		if(FEAT & FEAT_PLANE) {
+			outside_id = cast_planes(sc, rp, rd, hpos, hnrm);
+			if(outside_id != 0) surf = surface_of(sc, outside_id - 1);
+		}
+		return outside_id;
+	}
 	Walk w;
 	walk_start(sc.grid, start, rd, w);
 	int id = 0;
@@ -764,7 +825,7 @@ PT_DEV int cast_grid(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface&
 			GeoRef g = { sc.geo, sc.n, oi };
 			v4f p0 = g.plane(G_POS);
 			V3 p, q;
-			float distance = intersect(g, p0, rp, rd, p, q);
+			float distance = intersect<FEAT>(g, p0, rp, rd, p, q);
 			if(distance > 0 && distance < best && inside_box(p, w.lo, w.hi)) {
 				best = distance;
 				id = oi + 1;
@@ -778,10 +839,11 @@ PT_DEV int cast_grid(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface&
 	return id;
 }
 
+// The cast of the small passes (tile-cost probes, debug outputs, ray queries, the cast histogram): every feature compiled in.
 template <bool HASH>
 PT_DEV int cast(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface& surf, uint64_t& hash) {
-	if(sc.brute) return cast_all(sc, rp, rd, hpos, hnrm, surf);
-	return cast_grid<HASH>(sc, rp, rd, hpos, hnrm, surf, hash);
+	if(sc.brute) return cast_all<FEAT_EVERY>(sc, rp, rd, hpos, hnrm, surf);
+	return cast_grid<HASH, FEAT_EVERY>(sc, rp, rd, hpos, hnrm, surf, hash);
 }
 
 // ---- wave-cooperative grid cast ------------------------------------------------------------------
@@ -934,7 +996,7 @@ PT_DEV bool sphere_rejects(V3 rp, V3 rd, v4f p0) {
 
 // One chunk of up to 64 candidates of one kind (or of any, KIND_MIXED), one per lane, taken from list[base .. end).  Called by
 // the whole wavefront: the rendezvous between the atomic min and the winner's write-back must be reached by all 64 lanes.
-template <int KIND>
+template <int KIND, int FEAT>
 PT_DEV void coop_chunk(const Scene& sc, CoopShared& sh, const uint32_t* list, uint32_t base, uint32_t end, int lane) {
 PT_MARK("chunk_begin");
 	uint32_t i = base + (uint32_t)lane;
@@ -965,7 +1027,7 @@ PT_MARK("chunk_fetched");
 		v4f p1 = p0, p4 = p0;
 		if(KIND == KIND_MIXED) { p1 = g.plane(G_ROTINV); p4 = g.plane(G_SCALEINV); }
 		PT_TOCK_LANDED(sh, 9, tc);
-		distance = KIND == KIND_MIXED ? intersect_mixed(mixed_kind, g, p0, p1, p3, p4, rp, rd, pos, nrm, sc.obj_range, lo, hi) : intersect_kind<KIND>(g, p0, p3, rp, rd, pos, nrm);
+		distance = KIND == KIND_MIXED ? intersect_mixed<FEAT>(mixed_kind, g, p0, p1, p3, p4, rp, rd, pos, nrm, sc.obj_range, lo, hi) : intersect_kind<KIND>(g, p0, p3, rp, rd, pos, nrm);
 	}
 	PT_TOCK(sh, 3, tc);
 PT_MARK("chunk_intersected");
@@ -1046,38 +1108,42 @@ PT_MARK("chunk_end");
 }
 
 // Tests everything in the pool and empties it.  Whole wavefront.
+template <int FEAT>
 PT_DEV void coop_drain(const Scene& sc, CoopShared& sh, int lane) {
 PT_MARK("drain_begin");
 	const uint32_t total = uniform(sh.count[KIND_COUNT]);
 	if(total == 0) return;
 	if(total <= 64u) {
 		// one chunk of mixed kinds, whatever their order: straight from the pool
-		coop_chunk<KIND_MIXED>(sc, sh, sh.pool, 0, total, lane);
+		coop_chunk<KIND_MIXED, FEAT>(sc, sh, sh.pool, 0, total, lane);
 	} else {
 		uint32_t off[KIND_COUNT + 1];
 		off[0] = 0;
 		#pragma unroll
-		for(int k = 0; k < KIND_COUNT; k++) off[k + 1] = off[k] + uniform(sh.count[k]);
+		for(int k = 0; k < KIND_COUNT; k++) off[k + 1] = off[k] + ((FEAT & FEAT_PLANE) || k != KIND_PLANE ? uniform(sh.count[k]) : 0u);
 		for(uint32_t i = (uint32_t)lane; i < total; i += 64) {
 			uint32_t e = sh.pool[i];
 			uint32_t kind = (e >> 23) & 7u;
-			uint32_t base = kind == 0 ? off[0] : kind == 1 ? off[1] : kind == 2 ? off[2] : kind == 3 ? off[3] : kind == 4 ? off[4] : off[5];
+			uint32_t base = kind == 0 ? off[0] : kind == 1 ? off[1] : kind == 2 ? off[2] : kind == 3 ? off[3] : kind == 4 ? off[4] : (!(FEAT & FEAT_PLANE) || kind == 5) ? off[5] : off[6];
 			sh.sorted[base + atomicAdd(&sh.fill[kind], 1u)] = e;
 		}
 		wave_sync();
 		// Few candidates: chunks of mixed kinds cost less than a nearly empty chunk per kind.
 		if(total <= (uint32_t)COOP_MIX_ALL) {
-			for(uint32_t base = 0; base < total; base += 64) coop_chunk<KIND_MIXED>(sc, sh, sh.sorted, base, total, lane);
+			for(uint32_t base = 0; base < total; base += 64) coop_chunk<KIND_MIXED, FEAT>(sc, sh, sh.sorted, base, total, lane);
 		} else {
-			for(uint32_t base = off[0]; base < off[1]; base += 64) coop_chunk<KIND_SPHERE>(sc, sh, sh.sorted, base, off[1], lane);
-			for(uint32_t base = off[1]; base < off[2]; base += 64) coop_chunk<KIND_BOX>(sc, sh, sh.sorted, base, off[2], lane);
+			for(uint32_t base = off[0]; base < off[1]; base += 64) coop_chunk<KIND_SPHERE, FEAT>(sc, sh, sh.sorted, base, off[1], lane);
+			for(uint32_t base = off[1]; base < off[2]; base += 64) coop_chunk<KIND_BOX, FEAT>(sc, sh, sh.sorted, base, off[2], lane);
 			if(off[6] - off[2] <= (uint32_t)COOP_MIX_UNIT) {
-				for(uint32_t base = off[2]; base < off[6]; base += 64) coop_chunk<KIND_MIXED>(sc, sh, sh.sorted, base, off[6], lane);
+				for(uint32_t base = off[2]; base < off[6]; base += 64) coop_chunk<KIND_MIXED, FEAT>(sc, sh, sh.sorted, base, off[6], lane);
 			} else {
-				for(uint32_t base = off[2]; base < off[3]; base += 64) coop_chunk<KIND_BOX_ROTATED>(sc, sh, sh.sorted, base, off[3], lane);
-				for(uint32_t base = off[3]; base < off[4]; base += 64) coop_chunk<KIND_ELLIPSOID>(sc, sh, sh.sorted, base, off[4], lane);
-				for(uint32_t base = off[4]; base < off[5]; base += 64) coop_chunk<KIND_CYLINDER>(sc, sh, sh.sorted, base, off[5], lane);
-				for(uint32_t base = off[5]; base < off[6]; base += 64) coop_chunk<KIND_CONE>(sc, sh, sh.sorted, base, off[6], lane);
+				for(uint32_t base = off[2]; base < off[3]; base += 64) coop_chunk<KIND_BOX_ROTATED, FEAT>(sc, sh, sh.sorted, base, off[3], lane);
+				for(uint32_t base = off[3]; base < off[4]; base += 64) coop_chunk<KIND_ELLIPSOID, FEAT>(sc, sh, sh.sorted, base, off[4], lane);
+				for(uint32_t base = off[4]; base < off[5]; base += 64) coop_chunk<KIND_CYLINDER, FEAT>(sc, sh, sh.sorted, base, off[5], lane);
+				for(uint32_t base = off[5]; base < off[6]; base += 64) coop_chunk<KIND_CONE, FEAT>(sc, sh, sh.sorted, base, off[6], lane);
+			}
+			if(FEAT & FEAT_PLANE) {
+				for(uint32_t base = off[6]; base < off[7]; base += 64) coop_chunk<KIND_PLANE, FEAT>(sc, sh, sh.sorted, base, off[7], lane);
 			}
 		}
 	}
@@ -1101,8 +1167,10 @@ PT_DEV void coop_lane_reset(CoopLane& st) { st.walking = false; }
 // it was in.  The call returns as soon as fewer than COOP_MIN_WALKING lanes are still walking, so
 // the caller can shade the finished rays and hand their lanes new ones instead of idling them until
 // the longest walk of the wavefront ends; `done` tells which lanes have their result.
+template <int FEAT>
 PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active, bool fresh, CoopLane& st, V3 rp, V3 rd, V3& hpos,
                           V3& hnrm, Surface& surf, bool& done) {
+	int result = 0;
 	if(active && fresh) {
 		coop_lane_reset(st);
 		V3 start;
@@ -1113,11 +1181,12 @@ PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active
 			st.tx = full.tx; st.ty = full.ty; st.tz = full.tz;
 			st.dx = full.dx; st.dy = full.dy; st.dz = full.dz;
 			st.walking = true;
+		} else if(FEAT & FEAT_PLANE) {
+			result = cast_planes(sc, rp, rd, hpos, hnrm);      // the ray never meets the grid: the planes, and this lane is done
 		}
 		put6(sh.ray[lane], rp, rd);
 	}
 	bool walking = active && st.walking;
-	int result = 0;
 
 	if(lane == 0 && __ballot(walking) != 0) PT_STAT(9, 1);
 	while(__ballot(walking) != 0) {
@@ -1315,7 +1384,7 @@ PT_MARK("trip_filtered");
 			wave_sync();
 			if(uniform(sh.count[KIND_COUNT]) > (uint32_t)(COOP_POOL - 64 * COOP_ITEMS)) {
 				PT_TOCK(sh, 11, t0);
-				coop_drain(sc, sh, lane);
+				coop_drain<FEAT>(sc, sh, lane);
 				PT_TOCK(sh, 12, t0);
 			}
 		}
@@ -1323,7 +1392,7 @@ PT_MARK("trip_filtered");
 
 PT_MARK("expand_end");
 		// ---- test what is left in the pool ------------------------------------------------------------
-		coop_drain(sc, sh, lane);
+		coop_drain<FEAT>(sc, sh, lane);
 		PT_TOCK(sh, 12, t0);
 
 PT_MARK("verdict_begin");

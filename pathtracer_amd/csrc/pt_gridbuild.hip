@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kBlock) void pt_k_grid_count(ptl::GridBuildJob job)
 	const CellRange r = range_of(job, i);
 	const int tf = __float_as_int(job.geo[(size_t)i * ptl::REC_STRIDE + ptl::REC_DIM].w);
 	const int type = tf & 0xff, flags = tf >> 8;
-	const uint32_t kind = type == PT_GEOM_SPHERE ? ((flags & 2) ? 0u : 3u) : type == PT_GEOM_BOX ? ((flags & 1) ? 2u : 1u) : type == PT_GEOM_CYLINDER ? 4u : 5u;
+	const uint32_t kind = type == PT_GEOM_SPHERE ? ((flags & 2) ? 0u : 3u) : type == PT_GEOM_BOX ? ((flags & 1) ? 2u : 1u) : type == PT_GEOM_CYLINDER ? 4u : type == PT_GEOM_CONE ? 5u : 6u;
 	job.obj_range[2 * (size_t)i] = (uint32_t)r.a[0] | ((uint32_t)r.a[1] << 10) | ((uint32_t)r.a[2] << 20) | ((kind & 3u) << 30);
 	job.obj_range[2 * (size_t)i + 1] = (uint32_t)r.b[0] | ((uint32_t)r.b[1] << 10) | ((uint32_t)r.b[2] << 20) | ((kind >> 2) << 30);
 	for(int z = r.a[2]; z <= r.b[2]; z++) for(int y = r.a[1]; y <= r.b[1]; y++) for(int x = r.a[0]; x <= r.b[0]; x++)
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void pt_k_grid_order(ptl::GridBuildJob job,
 		}
 		const float4 p = job.geo[(size_t)id * ptl::REC_STRIDE];
 		uint32_t w[4];
-		ptl::pack_entry(p.x, p.y, p.z, p.w, tag, id, w);
+		ptl::pack_entry(p.x, p.y, p.z, job.bbox[id].w, tag, id, w);
 		job.cell_entries[k] = make_float4(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]));
 	}
 }

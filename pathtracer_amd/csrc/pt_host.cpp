@@ -83,11 +83,12 @@ void flatten_objects(const pt_object* objs, int n, float* records) {
 			case PT_GEOM_CONE: radius = tmax(dim.x, dim.y) * 0.5f + dim.z * 0.5f; break;
 		}
 
-		// symmetric AABB of the rotated corners (code/raycast.cpp:99-139)
+		// symmetric AABB of the rotated corners (code/raycast.cpp:99-139); a plane counts as a slab of 10^6 x 10^6 x 0
+		const f3 extent = o.type == PT_GEOM_PLANE ? f3{ 1000000, 1000000, 0 } : dim;
 		f3 lo = { FLT_MAX, FLT_MAX, FLT_MAX }, hi = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
 		for(int c = 0; c < 8; c++) {
 			f3 corner = { (c & 4) ? -0.5f : 0.5f, (c & 2) ? -0.5f : 0.5f, (c & 1) ? -0.5f : 0.5f };
-			f3 p = rotate(rot, dim * corner);
+			f3 p = rotate(rot, extent * corner);
 			lo = { tmin(lo.x, p.x), tmin(lo.y, p.y), tmin(lo.z, p.z) };
 			hi = { tmax(hi.x, p.x), tmax(hi.y, p.y), tmax(hi.z, p.z) };
 		}
@@ -98,13 +99,14 @@ void flatten_objects(const pt_object* objs, int n, float* records) {
 		f3 unit = { 1, 1, 1 };
 		if(o.type == PT_GEOM_CYLINDER) unit = { 2, 2, 2 };
 		if(o.type == PT_GEOM_CONE) unit = { 2, 2, 1 };
+		const bool plane = o.type == PT_GEOM_PLANE;      // preCalcObjects leaves a plane's scales alone (code/raycast.cpp:2081-2105)
 
 		put(r, PT_F_POS, pos);
 		r[PT_F_ROT] = rot.w; r[PT_F_ROT + 1] = rot.x; r[PT_F_ROT + 2] = rot.y; r[PT_F_ROT + 3] = rot.z;
 		r[PT_F_ROTINV] = rinv.w; r[PT_F_ROTINV + 1] = rinv.x; r[PT_F_ROTINV + 2] = rinv.y; r[PT_F_ROTINV + 3] = rinv.z;
 		put(r, PT_F_DIM, dim);
-		put(r, PT_F_SCALE, dim / unit);
-		put(r, PT_F_SCALEINV, unit / dim);
+		put(r, PT_F_SCALE, plane ? f3{ 0, 0, 0 } : dim / unit);
+		put(r, PT_F_SCALEINV, plane ? f3{ 0, 0, 0 } : unit / dim);
 		put(r, PT_F_COLOR, { gamma_decode(o.color[0]), gamma_decode(o.color[1]), gamma_decode(o.color[2]) });
 		put(r, PT_F_EMIT, { gamma_decode(o.emit_color[0]), gamma_decode(o.emit_color[1]), gamma_decode(o.emit_color[2]) });
 		put(r, PT_F_BBOX, bbox);
@@ -362,11 +364,27 @@ bool object_ranges(const float* records, int n, const GridDesc& g, std::vector<u
 		int32_t type, flags;
 		memcpy(&type, r + PT_F_TYPE, 4);
 		memcpy(&flags, r + PT_F_FLAGS, 4);
-		uint32_t kind = type == PT_GEOM_SPHERE ? ((flags & 2) ? 0u : 3u) : type == PT_GEOM_BOX ? ((flags & 1) ? 2u : 1u) : type == PT_GEOM_CYLINDER ? 4u : 5u;
+		uint32_t kind = type == PT_GEOM_SPHERE ? ((flags & 2) ? 0u : 3u) : type == PT_GEOM_BOX ? ((flags & 1) ? 2u : 1u) : type == PT_GEOM_CYLINDER ? 4u : type == PT_GEOM_CONE ? 5u : 6u;
 		(*ranges)[(size_t)i * 2] = a[0] | (a[1] << 10) | (a[2] << 20) | ((kind & 3u) << 30);
 		(*ranges)[(size_t)i * 2 + 1] = b[0] | (b[1] << 10) | (b[2] << 20) | ((kind >> 2) << 30);
 	}
 	return true;
+}
+
+// The normal of a plane: rot * (0, 0, 1), as getIntersection works it out for every test (code/raycast.cpp:887).
+void plane_normal(const float* record, float out[3]) {
+	const q4 rot = { record[PT_F_ROT], record[PT_F_ROT + 1], record[PT_F_ROT + 2], record[PT_F_ROT + 3] };
+	const f3 n = rotate(rot, f3{ 0, 0, 1 });
+	out[0] = n.x; out[1] = n.y; out[2] = n.z;
+}
+
+// Radius of a sphere about the entity's position that encloses it, for the cooperative cast's conservative filter (no result
+// depends on it, only which entities get the exact test).  A plane has none: infinity lets every ray through.
+float filter_radius(const float* record) {
+	int32_t type;
+	memcpy(&type, record + PT_F_TYPE, 4);
+	if(type == PT_GEOM_PLANE) return INFINITY;
+	return record[PT_F_BRADIUS];
 }
 
 // ---- screenshot encoding (code/app.cpp:1541-1547) ------------------------------------------------------

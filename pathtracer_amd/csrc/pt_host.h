@@ -51,6 +51,11 @@ bool build_grid(const float* records, int n, int hint, GridDesc* g, std::vector<
 // intersection kind (3 bits split over the two spare bit pairs).  False when a range does not fit.
 bool object_ranges(const float* records, int n, const GridDesc& g, std::vector<uint32_t>* ranges);
 
+// A plane's normal rot * (0, 0, 1) (code/raycast.cpp:887) from its flattened record.
+void plane_normal(const float* record, float out[3]);
+// Radius of a sphere about the entity's position that encloses it (the cooperative cast's conservative filter); infinite for a plane.
+float filter_radius(const float* record);
+
 // Screenshot encoding of one channel (floatToSrgb then colorFloatToInt, code/rt_math.cpp:3634-3640,351-353, as
 // code/app.cpp:1544 combines them) and the 255 smallest inputs in [0, 1] at which its output steps up to
 // 1 .. 255, found by bisection over float bit patterns (the expression is monotone).

@@ -8,7 +8,7 @@
 // same trip, and a lane whose pixel is finished pulls a new pixel from the wave's tile pool, so the
 // live rays stay compacted in the 64 lanes between bounces without ever going through memory.
 // The unit of work a lane takes is one RANGE of a pixel's samples (a pixel's samples are cut into
-// 2^ranges_log2 contiguous ranges): a lane sums its range in sample order in registers and stores
+// a few even, contiguous ranges): a lane sums its range in sample order in registers and stores
 // the sum; pt_k_resolve then folds a pixel's range sums in range order.  The order of every addition
 // is fixed by the inputs, so the image is a pure function of them (independent of wave scheduling,
 // grid size and GPU count), while the work units are short enough for the frame to end evenly.
@@ -177,9 +177,10 @@ PT_MARK("loop_begin");
 				g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
 				if(g >= (uint32_t)job.n_groups) { dry = true; break; }
 				// tiles are dealt in the order of the host's cost estimate, dearest first, so that the frame ends on cheap ones
-				const int local_tile = job.tile_order ? job.tile_order[g >> ranges_log2] : (int)(g >> ranges_log2);
+				const uint32_t g_tile = g >> ranges_log2, g_range = g & ((1u << ranges_log2) - 1u);
+				const int local_tile = job.tile_order ? job.tile_order[g_tile] : (int)g_tile;
 				const int tile = local_tile * job.part_count + job.part_index;
-				tile_range = (int)(g & ((1u << ranges_log2) - 1u));
+				tile_range = (int)g_range;
 				tile_x0 = (tile % job.tiles_x) * 8;
 				tile_y0 = (tile / job.tiles_x) * 8;
 				tile_slot0 = local_tile * kGroup;
@@ -303,14 +304,14 @@ PT_MARK("camera_end");
 PT_MARK("cast_begin");
 		if(MODE == CAST_GRID_COOP) {
 			// the whole wavefront takes part; lanes whose walk is not over yet stay in flight and resume
-			id = cast_grid_coop(sc, coop, lane, flying, fresh, walk_state, rp, rd, hp, hn, surf, landed);
+			id = cast_grid_coop<FEAT>(sc, coop, lane, flying, fresh, walk_state, rp, rd, hp, hn, surf, landed);
 			fresh = landed || !flying;
 			get6(coop.ray[lane], rp, rd);     // the ray waits in LDS during the cast, not in registers
 			PT_TOCK(coop, 14, t_loop);
 		} else {
 			if(flying) {
 				uint64_t unused = 0;
-				id = MODE == CAST_BRUTE ? cast_all<FEAT>(sc, rp, rd, hp, hn, surf) : cast_grid<false>(sc, rp, rd, hp, hn, surf, unused);
+				id = MODE == CAST_BRUTE ? cast_all<FEAT>(sc, rp, rd, hp, hn, surf) : cast_grid<false, FEAT>(sc, rp, rd, hp, hn, surf, unused);
 			}
 			PT_TOCK(coop, 14, t_loop);
 		}
@@ -366,7 +367,9 @@ PT_MARK("shade_end");
 	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, 0, false>(ptl::TraceJob); \
 	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, 0, true>(ptl::TraceJob); \
 	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, FEAT_ALL, false>(ptl::TraceJob); \
-	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, FEAT_ALL, true>(ptl::TraceJob);
+	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, FEAT_ALL, true>(ptl::TraceJob); \
+	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, FEAT_EVERY, false>(ptl::TraceJob); \
+	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, FEAT_EVERY, true>(ptl::TraceJob);
 #if defined(PT_UNIT_BRUTE)
 PT_BRUTE_VARIANTS()
 #elif defined(PT_SPLIT_BRUTE)
@@ -480,6 +483,62 @@ __global__ __launch_bounds__(kBlock) void pt_k_tile_cost(ptl::TraceJob job, int 
 	if(owned && probe == 0) cost[lt] = (uint16_t)(casts > 1023u ? 1023u : casts);
 }
 
+// Metrics pass: how many rays each camera sample's path casts (the bounce histogram of the harness's report).  One
+// thread per pixel slot retraces every sample of its pixel with the trace kernel's own device functions and streams,
+// so the paths are the frame's paths; the counts meet in a histogram in LDS and leave it with one atomic per bin and block.
+constexpr int kHistBins = 65;
+__global__ __launch_bounds__(kBlock) void pt_k_cast_histogram(ptl::TraceJob job, size_t slots, unsigned long long* histogram, int bins) {
+	__shared__ unsigned int local[kHistBins];
+	if(threadIdx.x < kHistBins) local[threadIdx.x] = 0;
+	__syncthreads();
+	const size_t slot = (size_t)blockIdx.x * kBlock + threadIdx.x;
+	const Scene sc = scene_view(job.scene);
+	const FrameRef fr = (FrameRef)job.frame;
+	int px = -1, py = -1;
+	if(slot < slots) {
+		if(job.compact) {
+			const int tile = (int)(slot / kGroup) * job.part_count + job.part_index, j = (int)(slot % kGroup);
+			px = (tile % job.tiles_x) * 8 + (j & 7);
+			py = (tile / job.tiles_x) * 8 + (j >> 3);
+		} else {
+			px = (int)(slot % (size_t)fr->width);
+			py = (int)(slot / (size_t)fr->width);
+		}
+	}
+	if(px >= 0 && px < fr->width && py < fr->height) {
+		const int t = (py % fr->tile_w) * fr->tile_w + (px % fr->tile_w);
+		const int base = sc.offsets[t], n_samples = sc.offsets[t + 1] - base;
+		int s0 = 0, s1 = n_samples;
+		uint64_t pass = 0;
+		if(job.frame_index >= 0 && n_samples > 0) { s0 = job.frame_index % n_samples; s1 = s0 + 1; pass = (uint64_t)(job.frame_index / n_samples); }
+		const int lens = fr->aperture != 0.0f ? lens_start(fr, px, py) : 0;
+		const V3 origin = pixel_origin_tab(job, fr, px, py);
+		for(int si = s0; si < s1; si++) {
+			V3 rp, rd;
+			camera_ray(sc, fr, origin, sc.samples[base + si], lens + si, rp, rd);
+			Rng rng;
+			sample_stream(fr, px, py, si, pass, rng);
+			V3 att = v3(1, 1, 1), col = v3(0, 0, 0);
+			int casts = 0;
+			for(int bounce = 0; bounce < fr->max_bounces; bounce++) {
+				V3 hp = v3(0, 0, 0), hn = v3(0, 0, 0);
+				uint64_t unused = 0;
+				Surface surf;
+				surf.m0 = (v4f)(0.0f); surf.m1 = (v4f){ 0.0f, 0.0f, 0.0f, 1.0f }; surf.rough = 0;
+				const int id = cast<false>(sc, rp, rd, hp, hn, surf, unused);
+				casts++;
+				if(!shade(sc, fr, id, surf, hp, hn, bounce, rp, rd, att, col, rng)) break;
+			}
+			atomicAdd(&local[casts < kHistBins ? casts : kHistBins - 1], 1u);
+		}
+	}
+	__syncthreads();
+	if(threadIdx.x < kHistBins && local[threadIdx.x] != 0) {
+		const int bin = (int)threadIdx.x < bins ? (int)threadIdx.x : bins - 1;
+		atomicAdd(&histogram[bin], (unsigned long long)local[threadIdx.x]);
+	}
+}
+
 // Debug pass: entity hit by, and grid cells visited by, the primary ray of camera sample 0 of
 // every pixel.  Same device functions as the trace kernel.
 __global__ __launch_bounds__(kBlock) void pt_k_primary(ptl::SceneDev scene, const ptl::FrameDev* frame, int32_t* hit_id, uint64_t* cell_hash) {
@@ -517,7 +576,7 @@ __global__ __launch_bounds__(kBlock) void pt_k_cast(ptl::SceneDev scene, int mod
 	V3 hp = v3(0, 0, 0), hn = v3(0, 0, 0);
 	uint64_t unused = 0;
 	Surface surf;
-	int id = mode == 1 ? cast_all<FEAT_ALL, false>(sc, rp, rd, hp, hn, surf) : cast<false>(sc, rp, rd, hp, hn, surf, unused);
+	int id = mode == 1 ? cast_all<FEAT_EVERY, false>(sc, rp, rd, hp, hn, surf) : cast<false>(sc, rp, rd, hp, hn, surf, unused);
 	if(id == 0) { hp = v3(0, 0, 0); hn = v3(0, 0, 0); }
 	hit_id[i] = id;
 	if(hit_pos) { hit_pos[3 * i] = hp.x; hit_pos[3 * i + 1] = hp.y; hit_pos[3 * i + 2] = hp.z; }
@@ -662,10 +721,14 @@ int coop_stats(unsigned long long* out16) {
 }
 
 namespace {
-enum { V_BRUTE_PLAIN = 0, V_BRUTE = 1, V_GRID_LANE = 2, V_GRID_COOP = 3, V_COUNT = 4 };
+enum { V_BRUTE_PLAIN = 0, V_BRUTE = 1, V_GRID_LANE = 2, V_GRID_COOP = 3, V_BRUTE_PLANES = 4, V_GRID_COOP_PLANES = 5, V_COUNT = 6 };
+static_assert(V_COUNT == ptl::kTraceVariants, "TraceCaps holds one entry per variant");
+// (the per-lane grid walk is the fallback and the A/B partner of the cooperative cast: one variant with everything in it)
 void (*const kTraceKernels[2][V_COUNT])(TraceJob) = {
-	{ pt_k_trace<CAST_BRUTE, 0, false>, pt_k_trace<CAST_BRUTE, FEAT_ALL, false>, pt_k_trace<CAST_GRID_LANE, FEAT_ALL, false>, pt_k_trace<CAST_GRID_COOP, FEAT_ALL, false> },
-	{ pt_k_trace<CAST_BRUTE, 0, true>, pt_k_trace<CAST_BRUTE, FEAT_ALL, true>, pt_k_trace<CAST_GRID_LANE, FEAT_ALL, true>, pt_k_trace<CAST_GRID_COOP, FEAT_ALL, true> } };
+	{ pt_k_trace<CAST_BRUTE, 0, false>, pt_k_trace<CAST_BRUTE, FEAT_ALL, false>, pt_k_trace<CAST_GRID_LANE, FEAT_EVERY, false>, pt_k_trace<CAST_GRID_COOP, FEAT_ALL, false>,
+	  pt_k_trace<CAST_BRUTE, FEAT_EVERY, false>, pt_k_trace<CAST_GRID_COOP, FEAT_EVERY, false> },
+	{ pt_k_trace<CAST_BRUTE, 0, true>, pt_k_trace<CAST_BRUTE, FEAT_ALL, true>, pt_k_trace<CAST_GRID_LANE, FEAT_EVERY, true>, pt_k_trace<CAST_GRID_COOP, FEAT_ALL, true>,
+	  pt_k_trace<CAST_BRUTE, FEAT_EVERY, true>, pt_k_trace<CAST_GRID_COOP, FEAT_EVERY, true> } };
 }
 
 hipError_t query_trace_caps(TraceCaps* caps) {
@@ -688,8 +751,9 @@ hipError_t query_trace_caps(TraceCaps* caps) {
 hipError_t launch_trace(const TraceJob& job, const TraceCaps& caps, hipStream_t stream, int* grid_blocks_out) {
 	static const bool lane_walk = getenv("PT_GRID_PER_LANE") != nullptr;     // A/B switches: per-lane grid walk,
 	static const bool full_brute = getenv("PT_BRUTE_FULL") != nullptr;       // the all-features brute-force variant for every scene
-	const int variant = job.scene.brute ? (job.scene.features == 0 && !full_brute ? V_BRUTE_PLAIN : V_BRUTE)
-	                                    : (job.scene.coop && !lane_walk ? V_GRID_COOP : V_GRID_LANE);
+	const bool planes = (job.scene.features & FEAT_PLANE) != 0;       // a scene with planes runs the variants that know them
+	const int variant = job.scene.brute ? (planes ? V_BRUTE_PLANES : job.scene.features == 0 && !full_brute ? V_BRUTE_PLAIN : V_BRUTE)
+	                                    : (job.scene.coop && !lane_walk ? (planes ? V_GRID_COOP_PLANES : V_GRID_COOP) : V_GRID_LANE);
 	// persistent launch: every resident wave pulls groups of 64 work items until the partition is drained
 	long blocks = ((long)job.n_groups + 3) / 4;
 	long resident = (long)caps.cus * caps.blocks_per_cu[variant];
@@ -716,6 +780,12 @@ hipError_t launch_resolve(const TraceJob& job, size_t slots, hipStream_t stream)
 hipError_t launch_finished(const TraceJob& job, size_t slots, uint8_t* mask, hipStream_t stream) {
 	if(slots == 0) return hipSuccess;
 	hipLaunchKernelGGL(pt_k_finished, dim3((unsigned)((slots + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, job, slots, mask);
+	return hipGetLastError();
+}
+
+hipError_t launch_cast_histogram(const TraceJob& job, size_t slots, unsigned long long* histogram, int bins, hipStream_t stream) {
+	if(slots == 0) return hipSuccess;
+	hipLaunchKernelGGL(pt_k_cast_histogram, dim3((unsigned)((slots + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, job, slots, histogram, bins);
 	return hipGetLastError();
 }
 

@@ -15,7 +15,7 @@ struct Vec { float x, y, z; };
 // 64 bytes, what only a hit needs (rotation and scale back to world space, the material) in the second.  (Measured on the
 // 100 000-entity scene: the bytes fetched per frame are the same as with the two halves interleaved - a miss in L2 brings
 // the whole line in either way.)
-//   REC_POS pos.xyz | bounding-sphere radius     REC_ROTINV rotInverse (w,x,y,z)     REC_DIM dim.xyz | type + flags<<8 (int bits)
+//   REC_POS pos.xyz | bounding-sphere radius     REC_ROTINV rotInverse (w,x,y,z); a plane: its normal rot * (0,0,1)     REC_DIM dim.xyz | type + flags<<8 (int bits)
 //   REC_SCALEINV dimScaleInverse.xyz | -         (an unrotated box keeps its corners pos - dim/2, pos + dim/2 in REC_ROTINV, REC_SCALEINV)
 //   REC_ROT rot (w,x,y,z)     REC_SCALE dimScale.xyz | roughness     REC_COLOR colorLinear.rgb | reflectionMod     REC_EMIT emitColorLinear.rgb | refractiveIndex
 enum { REC_POS = 0, REC_ROTINV = 1, REC_DIM = 2, REC_SCALEINV = 3, REC_ROT = 4, REC_SCALE = 5, REC_COLOR = 6, REC_EMIT = 7, REC_SLOTS = 8 };
@@ -86,10 +86,12 @@ struct SceneDev {
 	const float2* disc;
 	const float2* samples;
 	const int32_t* offsets;     // tile_w^2 + 1 sample offsets
+	const uint32_t* plane_ids;  // the entities that are planes, ascending (every ray that misses the grid tests them all)
+	int n_planes;
 	int n;
 	int brute;
 	int coop;                   // 1: the wave-cooperative cast may be used (ranges fit their packing)
-	int features;               // FEAT_* bits (pt_device.h) of what the entities need: unit-space kinds, glass, roughness
+	int features;               // FEAT_* bits (pt_device.h) of what the entities need: unit-space kinds, glass, roughness, planes
 	GridDev grid;
 };
 
@@ -113,7 +115,11 @@ struct TraceJob {
 	const float* row_frac;
 	uint32_t serial;            // marks the range sums of this launch (31 bits); top bit set: launch the kernel twin whose sums bypass the caches on
 	                            // their way to memory, so that a snapshot copied out while the frame is being traced finds the finished ones
-	int ranges_log2;            // a pixel's samples are summed in 2^ranges_log2 contiguous ranges
+	int ranges_log2;            // a pixel's samples are summed in 2^ranges_log2 even, contiguous ranges.  (Ranges of falling length -
+	                            // halves, or even parts with the last one cut into 8, 4 and 4 samples - dealt so that a launch ends on
+	                            // the short ones were built and measured: an eighth of the demo frame took 0.32 - 0.36 ms instead of
+	                            // 0.31; a long first range makes the dearest tile's item the critical path, and the extra groups cost
+	                            // what the finer end saves.)
 	float* fb;                  // row-major image, or tile-major [local tile][64][3] when compact
 	float* accum;               // progressive accumulation buffer (same layout as fb), may be null
 	const int32_t* tile_order;  // owned tiles in the order they are dealt (dearest first), or null for index order
@@ -131,7 +137,8 @@ struct TraceJob {
 
 // What a launch of the persistent trace kernel needs to know of the device: filled once per context, under that
 // context's device (compute units, resident workgroups per unit of each kernel variant).
-struct TraceCaps { int cus; int blocks_per_cu[4]; };
+constexpr int kTraceVariants = 6;
+struct TraceCaps { int cus; int blocks_per_cu[kTraceVariants]; };
 hipError_t query_trace_caps(TraceCaps* caps);
 hipError_t launch_trace(const TraceJob& job, const TraceCaps& caps, hipStream_t stream, int* grid_blocks_out);
 hipError_t launch_resolve(const TraceJob& job, size_t slots, hipStream_t stream);
@@ -139,6 +146,8 @@ hipError_t launch_resolve(const TraceJob& job, size_t slots, hipStream_t stream)
 // launch_resolve wrote), 0 for the others.
 hipError_t launch_finished(const TraceJob& job, size_t slots, uint8_t* mask, hipStream_t stream);
 hipError_t launch_tile_cost(const TraceJob& job, int local_tiles, uint16_t* cost, hipStream_t stream);   // cost: ray casts of 16 probe paths per owned tile, at most 1023
+// Metrics: histogram[min(k, bins - 1)] += camera samples of the job's partition whose path casts k rays (k up to 64; bins >= 2, zeroed by the caller)
+hipError_t launch_cast_histogram(const TraceJob& job, size_t slots, unsigned long long* histogram, int bins, hipStream_t stream);
 hipError_t launch_primary_aov(const SceneDev& sc, const FrameDev* fr, int width, int height, int32_t* hit_id, uint64_t* cell_hash, hipStream_t stream);
 // mode 0: the tracer's cast (brute force under the scene's threshold, else the grid walk); 1: the editor's pick, every
 // entity tested whatever the scene's size and whether or not the ray meets the grid (code/app.cpp:1637)
@@ -157,7 +166,7 @@ hipError_t launch_assemble(const float* parts, size_t stride, int part_count, in
 // Device-side grid build (pt_gridbuild.hip).
 struct GridBuildJob {
 	const float4* geo;          // entity records (position | bounding radius in slot 0, type + flags in slot 3)
-	const float4* bbox;         // world-space bounding-box extents of every entity
+	const float4* bbox;         // world-space bounding-box extents of every entity | radius of the sphere the cooperative cast's filter tests
 	int n;
 	GridDev grid;
 	uint32_t* obj_range;        // out: 2 words per entity

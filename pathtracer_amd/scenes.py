@@ -8,7 +8,7 @@ import math
 
 import numpy as np
 
-from .api import (PT_GEOM_BOX, PT_GEOM_CONE, PT_GEOM_CYLINDER, PT_GEOM_SPHERE, make_object,
+from .api import (PT_GEOM_BOX, PT_GEOM_CONE, PT_GEOM_CYLINDER, PT_GEOM_PLANE, PT_GEOM_SPHERE, make_object,
                   make_world)
 
 _M = (1 << 64) - 1
@@ -193,4 +193,30 @@ def aligned_boxes_scene():
             shade = 0.35 + 0.04 * (i + 4 * j)
             refl = 1.0 if (i + j) % 5 == 0 else 0.0
             objs.append(make_object((x0 + 6, y0 + 6, top / 2), (12, 12, top), PT_GEOM_BOX, color=(shade, 0.6, 1 - shade), refl=refl))
+    return world, objs
+
+
+def _axis_quat(axis, degrees):
+    a = math.radians(degrees) / 2
+    return (math.cos(a), axis[0] * math.sin(a), axis[1] * math.sin(a), axis[2] * math.sin(a))
+
+
+def planes_small_scene():
+    """The demo scene with the reference's fifth primitive added (GEOM_TYPE_PLANE, code/raycast.cpp:885-889): a ground
+    plane under the ground box and a tilted mirror plane behind the sphere.  Fewer than ten entities: every cast
+    tests every entity, the planes without a bounding-sphere test, and rays that miss the grid test the planes only."""
+    world, objs = default_scene()
+    objs.append(make_object((0, 0, -1.5), (1, 1, 1), PT_GEOM_PLANE, color=(0.6, 0.5, 0.4)))
+    objs.append(make_object((0, 30, 10), (1, 1, 1), PT_GEOM_PLANE, rot=_axis_quat((1, 0, 0), 70.0), color=(0.8, 0.8, 0.9), refl=0.85))
+    return world, objs
+
+
+def planes_grid_scene(seed=13, n=30):
+    """A grid scene (every kind and material) with three planes: one below the grid (its list entries are clamped into
+    the bottom layer of cells, and it is what rays that miss the grid hit), one cutting through the grid at a slant
+    (a mirror), one upright behind the cluster (diffuse, rough)."""
+    world, objs = mixed_scene(seed=seed, n=n)
+    objs.insert(3, make_object((0, 0, -2.0), (2, 2, 2), PT_GEOM_PLANE, color=(0.55, 0.6, 0.5)))
+    objs.insert(11, make_object((2, 3, 4.0), (1, 1, 1), PT_GEOM_PLANE, rot=_axis_quat((0.6, 0.8, 0), 38.0), color=(0.85, 0.85, 0.85), refl=1.0))
+    objs.append(make_object((0, 26, 0), (1, 1, 1), PT_GEOM_PLANE, rot=_axis_quat((1, 0, 0), 90.0), color=(0.4, 0.5, 0.7), rough=0.4))
     return world, objs

@@ -53,8 +53,13 @@ CASES = {
     "plain9": (lambda: scenes.plain_scene(seed=5, n=8), 10, 10),
     # upright boxes whose faces all lie on cell bounds (cells of 6 x 6 x 1): hit points on a cell's bound or an ulp beside it
     "aligned_boxes": (lambda: scenes.aligned_boxes_scene(), 14, 10),
+    # the reference's fifth primitive, the infinite plane: tested by every ray that misses the grid, never by a bounding sphere,
+    # and listed in whole layers of grid cells - in a brute-force scene, in a grid scene, and the small scene forced through the grid
+    "planes_small": (lambda: scenes.planes_small_scene(), 10, 10),
+    "planes_grid": (lambda: scenes.planes_grid_scene(), 10, 10),
+    "planes_small_grid": (lambda: scenes.planes_small_scene(), 10, 0),
 }
-ROUGH_FREE = {"default", "default_grid", "plain9", "aligned_boxes"}
+ROUGH_FREE = {"default", "default_grid", "plain9", "aligned_boxes", "planes_small", "planes_small_grid"}
 
 
 def settings_for(name, w, h, spp, bounces, seed=4242, **kw):
@@ -138,7 +143,8 @@ def test_primary_ids_and_cell_hashes(gpu, name):
                                                    ("mixed40", 160, 90, 16, 8), ("glass", 160, 90, 16, 32),
                                                    ("crowded", 128, 72, 4, 8), ("dense2k", 128, 72, 4, 8),
                                                    ("small_mixed", 160, 90, 16, 16), ("plain9", 160, 90, 16, 8),
-                                                   ("aligned_boxes", 160, 90, 16, 8)])
+                                                   ("aligned_boxes", 160, 90, 16, 8), ("planes_small", 160, 90, 16, 8),
+                                                   ("planes_grid", 160, 90, 16, 8), ("planes_small_grid", 96, 54, 16, 8)])
 def test_image_parity(gpu, name, w, h, spp, bounces):
     world, objs = CASES[name][0]()
     st = settings_for(name, w, h, spp, bounces)
@@ -162,7 +168,8 @@ def test_image_parity(gpu, name, w, h, spp, bounces):
 
 
 @pytest.mark.parametrize("name,w,h,spp,ranges", [("default", 160, 90, 64, 0), ("default", 160, 90, 64, 1), ("default", 160, 90, 64, 8),
-                                                  ("default_grid", 96, 54, 40, 16), ("glass", 96, 54, 64, 4), ("default", 64, 36, 4, 16)])
+                                                  ("default_grid", 96, 54, 40, 16), ("glass", 96, 54, 64, 4), ("default", 64, 36, 4, 16),
+                                                  ("small_mixed", 160, 90, 32, 2)])
 def test_sample_range_sums(gpu, name, w, h, spp, ranges):
     """A pixel's samples are added range by range and the range sums in range order: the device's work
     items are those ranges (different lanes, any order in time), the oracle adds in the same order, so
@@ -184,6 +191,30 @@ def test_sample_range_sums(gpu, name, w, h, spp, ranges):
     assert np.abs(img.astype(np.float64) - one).max() <= 4e-6, "range sums may differ from one sequence by rounding only"
     expect = api.load_core().pt_sample_ranges(C.byref(st))
     assert expect == (ranges if ranges else 4)
+
+
+@pytest.mark.parametrize("name,w,h,spp,bounces", [("default", 160, 90, 16, 8), ("glass", 96, 54, 16, 32), ("mixed40", 96, 54, 16, 8)])
+def test_cast_histogram(gpu, name, w, h, spp, bounces):
+    """The harness's bounce histogram (pt_cast_histogram): how many rays each camera sample's path casts, against the
+    oracle's count of the same paths; the bins add up to the frame's paths and, weighted, to its rays."""
+    world, objs = CASES[name][0]()
+    st = settings_for(name, w, h, spp, bounces)
+    gpu.render(world, objs, st)
+    stats = gpu.stats()
+    hist = gpu.cast_histogram()
+    sc = OracleScene(world, objs, st)
+    sc.render(policy=3, threads=1)
+    want = sc.cast_histogram()
+    sc.close()
+    assert hist[0] == 0 and int(hist.sum()) == stats.paths
+    assert int((hist * np.arange(hist.size, dtype=np.uint64)).sum()) == stats.rays
+    assert (hist[bounces + 1:] == 0).all()
+    if name in ROUGH_FREE:
+        assert (hist == want).all()
+    else:       # Oren-Nayar's libm calls can move an attenuation to exactly zero or not: path lengths may differ for a few paths
+        assert np.abs(hist.astype(np.int64) - want.astype(np.int64)).sum() <= max(2, int(EDGE_FRACTION * stats.paths))
+    few = gpu.cast_histogram(bins=4)
+    assert (few[:3] == hist[:3]).all() and int(few[3]) == int(hist[3:].sum())
 
 
 def test_per_sample_radiance_via_progressive_frames(gpu):
@@ -237,7 +268,7 @@ def test_reference_golden_vectors_on_gpu(gpu):
     """Straight against the reference's own outputs (tests/golden): casts through the prepared scene
     and pinhole primary hits."""
     gold = np.load(GOLD)
-    for name in ("default", "mixed40", "glass"):
+    for name in ("default", "mixed40", "glass", "planes_small", "planes_grid"):
         blob = gold[name + "_objects"].tobytes()
         n = len(blob) // C.sizeof(api.pt_object)
         objs = [api.pt_object.from_buffer_copy(blob, i * C.sizeof(api.pt_object)) for i in range(n)]
@@ -822,9 +853,12 @@ def test_unread_launches_do_not_pile_up_events(gpu):
 
 def test_argument_errors(gpu):
     world, objs = scenes.default_scene()
-    bad = make_object((0, 0, 0), (1, 1, 1), api.PT_GEOM_PLANE)
-    with pytest.raises(api.PtError, match="not supported"):
+    bad = make_object((0, 0, 0), (1, 1, 1), 5)            # one past GEOM_TYPE_PLANE
+    with pytest.raises(api.PtError, match="unknown geometry type"):
         gpu.prepare(world, objs + [bad], default_settings())
+    only_planes = [make_object((0, 0, 0), (1, 1, 1), api.PT_GEOM_PLANE)]
+    with pytest.raises(api.PtError, match="unusable grid"):     # the grid's extent comes from the entities that are not planes
+        gpu.prepare(world, only_planes, default_settings())
     with pytest.raises(api.PtError):
         gpu.prepare(world, objs, default_settings(width=0))
     with pytest.raises(api.PtError):

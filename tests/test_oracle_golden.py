@@ -74,7 +74,7 @@ def test_raw_intersectors(gold, oracle_lib):
     same_bits(rl, gold["optics_reflect"], "reflect")
 
 
-@pytest.mark.parametrize("name", ["default", "mixed40", "glass"])
+@pytest.mark.parametrize("name", ["default", "mixed40", "glass", "planes_small", "planes_grid"])
 def test_scene_stages(gold, oracle_lib, name):
     world, objs, st = load_case(gold, name)
     sc = OracleScene(world, objs, st)
@@ -122,7 +122,7 @@ def test_scene_stages(gold, oracle_lib, name):
     sc.close()
 
 
-@pytest.mark.parametrize("name", ["default", "mixed40", "glass"])
+@pytest.mark.parametrize("name", ["default", "mixed40", "glass", "planes_small", "planes_grid"])
 def test_full_image(gold, oracle_lib, name):
     """Whole pipeline under the per-job seed policy equals the reference image word for word."""
     world, objs, st = load_case(gold, name)
