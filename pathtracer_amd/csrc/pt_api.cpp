@@ -240,7 +240,7 @@ int grid_build_device(pt_ctx* c, const std::vector<float>& rec, int n, const pt:
 	PT_HIP(c, hipMemcpyAsync(&total, job.cell_start + cells, 4, hipMemcpyDeviceToHost, c->stream));
 	PT_HIP(c, hipMemcpyAsync(&longest, job.longest, 4, hipMemcpyDeviceToHost, c->stream));
 	PT_HIP(c, hipStreamSynchronize(c->stream));
-	if(longest > kLongestDeviceList) return PT_OK;
+	if(longest > kLongestDeviceList || total > ptl::CELL_START_MASK) return PT_OK;
 	PT_HIP(c, c->cell_items.reserve(((size_t)total + 1) * 4));
 	PT_HIP(c, c->cell_entries.reserve(((size_t)total + 1) * 16));
 	job.cell_items = c->cell_items.as<uint32_t>();
@@ -363,7 +363,7 @@ int prepare(pt_ctx* c) {
 		const ptl::GridDev layout = grid_dev(gd);
 		reorder_lists(layout, true, &cell_start, &cell_items);
 		item_total = cell_items.size();
-		if((rc = upload(c, c->cell_start, cell_start.data(), cell_start.size() * 4))) return rc;
+		if(item_total > ptl::CELL_START_MASK) return fail(c, PT_ERR_LIMIT, "the grid's cell lists hold %zu entries, more than the %u an index into them may address", item_total, ptl::CELL_START_MASK);
 		if((rc = upload(c, c->cell_items, cell_items.data(), cell_items.size() * 4))) return rc;
 		std::vector<uint32_t> ranges;
 		coop = pt::object_ranges(rec.data(), n, gd, &ranges);
@@ -374,7 +374,9 @@ int prepare(pt_ctx* c) {
 		for(int64_t cell = 0; cell < cells; cell++) {
 			uint32_t at[3];
 			ptl::grid_cell_coords(layout, (size_t)cell, at);
-			for(uint32_t k = cell_start[(size_t)cell]; k < cell_start[(size_t)cell + 1]; k++) {
+			uint32_t all_listed = 63u;       // per face: every entity of this list is listed across it too (ptl::CELL_FLAG_SHIFT)
+			const uint32_t k0 = cell_start[(size_t)cell], k1 = cell_start[(size_t)cell + 1];
+			for(uint32_t k = k0; k < k1; k++) {
 				const uint32_t id = cell_items[k];
 				const float* r = rec.data() + (size_t)id * PT_F_STRIDE;
 				const uint32_t lo = ranges[(size_t)id * 2], hi = ranges[(size_t)id * 2 + 1];
@@ -386,8 +388,12 @@ int prepare(pt_ctx* c) {
 				uint32_t w[4];
 				ptl::pack_entry(r[PT_F_POS], r[PT_F_POS + 1], r[PT_F_POS + 2], pt::filter_radius(r), tag, id, w);
 				memcpy(entries.data() + (size_t)k * 4, w, 16);
+				all_listed &= tag >> 3;
 			}
+			// (in place: cell k0 is not read again, the next cell's k0 is this cell's k1, taken above before any flag lands on it)
+			if(k1 > k0) cell_start[(size_t)cell] = k0 | (all_listed << ptl::CELL_FLAG_SHIFT);
 		}
+		if((rc = upload(c, c->cell_start, cell_start.data(), cell_start.size() * 4))) return rc;
 		if((rc = upload(c, c->cell_entries, entries.data(), entries.size() * 4))) return rc;
 	}
 	if(!tables_kept) {
@@ -1611,6 +1617,7 @@ int pt_debug_grid(pt_ctx* c, uint32_t* cell_start, int cell_capacity, uint32_t* 
 		std::vector<uint32_t> start(cells + 1, 0), list(items, 0);
 		PT_HIP(c, hipMemcpy(start.data(), c->cell_start.p, (cells + 1) * 4, hipMemcpyDeviceToHost));
 		if(items > 0) PT_HIP(c, hipMemcpy(list.data(), c->cell_items.p, items * 4, hipMemcpyDeviceToHost));
+		for(uint32_t& v : start) v &= ptl::CELL_START_MASK;      // the flags above the index are the device's own business
 		reorder_lists(c->job.scene.grid, false, &start, &list);
 		if(cell_start) memcpy(cell_start, start.data(), (cells + 1) * 4);
 		if(cell_items && items > 0) memcpy(cell_items, list.data(), items * 4);

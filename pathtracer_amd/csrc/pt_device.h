@@ -819,7 +819,7 @@ PT_DEV int cast_grid(const Scene& sc, V3 rp, V3 rd, V3& hpos, V3& hnrm, Surface&
 	do {
 		if(HASH) hash = hash_cell(hash, w.cz * sc.grid.cnt[1] * sc.grid.cnt[0] + w.cy * sc.grid.cnt[0] + w.cx);     // the reference's cell index
 		const int cell = w.cx * sc.grid.stride[0] + w.cy * sc.grid.stride[1] + w.cz * sc.grid.stride[2];           // where the cell sits here (ptl::grid_layout)
-		uint32_t k0 = sc.cell_start[cell], k1 = sc.cell_start[cell + 1];
+		uint32_t k0 = sc.cell_start[cell] & ptl::CELL_START_MASK, k1 = sc.cell_start[cell + 1] & ptl::CELL_START_MASK;
 		for(uint32_t k = k0; k < k1; k++) {
 			int oi = (int)sc.cell_items[k];
 			GeoRef g = { sc.geo, sc.n, oi };
@@ -1248,6 +1248,18 @@ PT_MARK("walk_begin");
 			}
 			#pragma unroll
 			for(int j = 0; j < COOP_CELLS; j++) { ka[j] = sc.cell_start[pc[j]]; kb[j] = sc.cell_start[pc[j] + 1]; }
+			// A cell whose every entity is also listed in the cell the ray comes from holds nothing new: its list is skipped (the
+			// flags ride above the list's first index, ptl::CELL_FLAG_SHIFT; the segment's first cell has no face and no such bit).
+			#pragma unroll
+			for(int j = 0; j < COOP_CELLS; j++) {
+#ifndef PT_COOP_NO_CELL_SKIP
+				const bool repeat = (((ka[j] >> ptl::CELL_FLAG_SHIFT) >> fc[j]) & 1u) != 0u;
+#else
+				const bool repeat = false;
+#endif
+				ka[j] &= ptl::CELL_START_MASK;
+				kb[j] = repeat ? ka[j] : kb[j] & ptl::CELL_START_MASK;
+			}
 		}
 		PT_TOCK_ISSUED(sh, 6, t0);
 		PT_TOCK_LANDED(sh, 7, t0);

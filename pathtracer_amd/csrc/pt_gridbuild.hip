@@ -133,7 +133,8 @@ __global__ __launch_bounds__(kBlock) void pt_k_grid_fill(ptl::GridBuildJob job) 
 __global__ __launch_bounds__(kBlock) void pt_k_grid_order(ptl::GridBuildJob job, size_t cells) {
 	const size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
 	if(c >= cells) return;
-	const uint32_t k0 = job.cell_start[c], k1 = job.cell_start[c + 1];
+	// (the neighbour thread may already have put its flags into cell_start[c + 1]: they are masked off)
+	const uint32_t k0 = job.cell_start[c] & ptl::CELL_START_MASK, k1 = job.cell_start[c + 1] & ptl::CELL_START_MASK;
 	uint32_t* list = job.cell_items;
 	for(uint32_t k = k0 + 1; k < k1; k++) {              // insertion sort: lists are short
 		const uint32_t id = list[k];
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(kBlock) void pt_k_grid_order(ptl::GridBuildJob job,
 	if(!job.cell_entries) return;
 	uint32_t at[3];
 	ptl::grid_cell_coords(job.grid, c, at);
+	uint32_t all_listed = 63u;            // per face: every entity of this list is listed across it too
 	for(uint32_t k = k0; k < k1; k++) {
 		const uint32_t id = list[k];
 		const uint32_t lo = job.obj_range[2 * (size_t)id], hi = job.obj_range[2 * (size_t)id + 1];
@@ -156,7 +158,9 @@ __global__ __launch_bounds__(kBlock) void pt_k_grid_order(ptl::GridBuildJob job,
 		uint32_t w[4];
 		ptl::pack_entry(p.x, p.y, p.z, job.bbox[id].w, tag, id, w);
 		job.cell_entries[k] = make_float4(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]));
+		all_listed &= tag >> 3;
 	}
+	if(k1 > k0 && all_listed != 0) job.cell_start[c] = k0 | (all_listed << ptl::CELL_FLAG_SHIFT);
 }
 
 }  // namespace

@@ -384,6 +384,14 @@ float filter_radius(const float* record) {
 	int32_t type;
 	memcpy(&type, record + PT_F_TYPE, 4);
 	if(type == PT_GEOM_PLANE) return INFINITY;
+#ifndef PT_LOOSE_FILTER_RADIUS
+	// The reference's bounding radius of a cylinder or cone, max(dx, dy) / 2 + dz / 2 (code/raycast.cpp:87-92), is generous: the
+	// point farthest from the centre is on the rim of a cap, sqrt((max(dx, dy) / 2)^2 + (dz / 2)^2) away.  (Rounded up.)
+	if(type == PT_GEOM_CYLINDER || type == PT_GEOM_CONE) {
+		const double rim = (double)tmax(record[PT_F_DIM], record[PT_F_DIM + 1]) * 0.5, half = (double)record[PT_F_DIM + 2] * 0.5;
+		return (float)(sqrt(rim * rim + half * half) * 1.000001);
+	}
+#endif
 	return record[PT_F_BRADIUS];
 }
 

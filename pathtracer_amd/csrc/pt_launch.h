@@ -47,6 +47,13 @@ __host__ __device__ inline void grid_cell_coords(const GridDev& g, size_t cell, 
 	for(int a = 0; a < 3; a++) at[a] = (uint32_t)((cell / (size_t)g.stride[a]) % (size_t)g.cnt[a]);
 }
 
+// cell_start[c] holds, above the 26 bits of the list's first index, six flags: bit 26 + f set = every entity of cell c's list is
+// also listed in the neighbour cell across face f (-x +x -y +y -z +z).  A ray that enters c through f from a cell whose list
+// the cooperative cast has just collected finds nothing new in c and skips its list (in scenes of flat cells, where entities span
+// many layers, most lists a ray meets are such repeats).  Every reader masks the flags off; cell_start[cells] carries none.
+constexpr uint32_t CELL_START_MASK = 0x03ffffffu;
+constexpr int CELL_FLAG_SHIFT = 26;
+
 // A list entry of the cooperative cast, 16 bytes: the entity's bounding sphere, its intersection kind (tag bits 0..2), in which
 // of the six neighbour cells it is listed as well (tag bits 3..8: -x +x -y +y -z +z) - and its id, so that collecting
 // candidates reads one array, not two.  The id (23 bits) rides where the sphere can spare bits: bits 0..6 in tag bits 9..15,
