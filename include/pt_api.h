@@ -218,6 +218,13 @@ int pt_cast_histogram(pt_ctx* ctx, uint64_t* histogram, int bins);
  * No counterpart in the reference. */
 int pt_debug_coop_stats(pt_ctx* ctx, unsigned long long* counters16);
 
+/* Debug read-back of the cost estimate the prepared scene's 8x8 tiles are dealt by (dearest first): ray casts of sixteen
+ * probe paths per owned tile, in the partition's tile order (local tile t is image tile t * part_count + part_index),
+ * capped at 1023.  No counterpart in the reference (its tile jobs go out in a fixed spiral, code/app.cpp:1359-1419); tests
+ * use it to place their comparisons where the frame is dearest.  tiles receives the count (0 when the partition owns fewer
+ * than two tiles); cost may be NULL. */
+int pt_debug_tile_cost(pt_ctx* ctx, uint16_t* cost, int capacity, int* tiles);
+
 /* Debug read-back of the uniform grid the prepared scene uses (the reference's per-cell ObjectLists,
  * code/app.cpp:1278-1354, in CSR form; built on the device for scenes of 4096 entities or more, on
  * the host otherwise; the environment variable PT_GRID_BUILD=host|device overrides the choice).

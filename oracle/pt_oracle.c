@@ -182,6 +182,7 @@ typedef struct pto_scene {
 	 * that started outside.  Under PT_SEED_PER_JOB (the reference's structure) the oracle does the same, from `false` at the
 	 * start of every job; under PT_SEED_PER_SAMPLE, whose paths are independent by definition, every ray starts from `false`. */
 	int sticky_outside, outside_state;
+	int n_planes; int* plane_ids;     /* the entities of type plane, ascending: what a ray that misses the grid tests */
 } pto_scene;
 
 /* ---- intersectors: code/raycast.cpp:390-585, code/rt_math.cpp:2343-2373 -------------------- */
@@ -864,8 +865,10 @@ static int cast_grid(pto_scene* s, v3 rp, v3 rd, v3* ipos, v3* inrm, uint64_t* h
 	int id = 0;
 	float min_d = FLT_MAX;
 	if(w.outside) {
-		for(int i = 0; i < s->n; i++) {
-			if(s->obj[i].type == PT_GEOM_PLANE) {
+		/* (the reference walks all objects and picks the planes out, code/raycast.cpp:938-939: the same planes in the same order) */
+		for(int k = 0; k < s->n_planes; k++) {
+			const int i = s->plane_ids[k];
+			{
 				v3 p = V3(0, 0, 0), q = V3(0, 0, 0);
 				float distance = get_intersection(s->obj + i, rp, rd, &p, &q, &s->cnt);
 				if(distance != -1) {
@@ -1175,7 +1178,7 @@ void pto_pcg_float(float from, float to, float prec, int n, float* out) { for(in
 void pto_scene_destroy(pto_scene* s) {
 	if(!s) return;
 	free(s->obj); free(s->dirs); free(s->disc); free(s->samples); free(s->offsets);
-	free(s->cell_start); free(s->cell_items);
+	free(s->cell_start); free(s->cell_items); free(s->plane_ids);
 	free(s);
 }
 
@@ -1198,6 +1201,8 @@ pto_scene* pto_scene_create(const pt_world* w, const pt_object* objs, int n, con
 		o->refl = objs[i].reflection_mod; o->ior = objs[i].refractive_index; o->rough = objs[i].roughness;
 		precalc_object(o);
 	}
+	s->plane_ids = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+	for(int i = 0; i < n; i++) if(s->obj[i].type == PT_GEOM_PLANE) s->plane_ids[s->n_planes++] = i;
 	precalc_world(s);
 	pcg32 rng;
 	pcg_seed(&rng, 0, st->seed);

@@ -177,6 +177,7 @@ def load_core():
     lib.pt_image_free.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.pt_pick_rays.argtypes = lib.pt_cast_rays.argtypes
     lib.pt_cast_rays_noalloc.argtypes = lib.pt_cast_rays.argtypes
+    lib.pt_debug_tile_cost.argtypes = [C.c_void_p, C.POINTER(C.c_uint16), C.c_int, C.POINTER(C.c_int)]
     lib.pt_cast_histogram.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
     lib.pt_debug_device_memory.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.pt_render_snapshot.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
@@ -362,6 +363,14 @@ class Renderer:
         bad = C.c_uint64(0)
         self._check(self.lib.pt_debug_arith_sweep(self.ctx, op, first_bits, count, C.byref(bad)), "pt_debug_arith_sweep")
         return bad.value
+
+    def tile_cost(self):
+        """Cost estimate of every owned 8x8 tile (pt_debug_tile_cost), in the partition's tile order."""
+        n = C.c_int(0)
+        self._check(self.lib.pt_debug_tile_cost(self.ctx, None, 0, C.byref(n)), "pt_debug_tile_cost")
+        cost = np.zeros(max(1, n.value), np.uint16)
+        self._check(self.lib.pt_debug_tile_cost(self.ctx, cost.ctypes.data_as(C.POINTER(C.c_uint16)), cost.size, C.byref(n)), "pt_debug_tile_cost")
+        return cost[:n.value]
 
     def cast_histogram(self, bins=65):
         """hist[k] = camera samples whose path casts k rays (pt_cast_histogram)."""

@@ -95,6 +95,7 @@ struct pt_ctx {
 	std::vector<int32_t> offsets_host;
 	uint32_t serial = 0;        // launch counter: marks the range sums each launch writes
 	int local_tiles = 0;
+	std::vector<uint16_t> tile_cost_host;   // the cost estimate of every owned tile, as the dealing order was made from it
 
 	// launch bookkeeping
 	std::vector<std::array<hipEvent_t, 3>> pending;   // events of launches not yet synchronised: start, trace done, resolve done
@@ -500,10 +501,12 @@ int prepare(pt_ctx* c) {
 	// the frame's last work items are cheap ones (a frame that ends on its dearest tiles idles most of the
 	// chip meanwhile).  Equal estimates go bottom-up: the lower rows of an image are usually the busier.
 	j.tile_order = nullptr;
+	c->tile_cost_host.clear();
 	if(c->local_tiles > 1 && getenv("PT_TILE_ORDER_INDEX") == nullptr) {
 		PT_HIP(c, c->tile_cost.reserve((size_t)c->local_tiles * 2));
 		PT_HIP(c, ptl::launch_tile_cost(j, c->local_tiles, c->tile_cost.as<uint16_t>(), c->stream));
-		std::vector<uint16_t> cost((size_t)c->local_tiles);
+		std::vector<uint16_t>& cost = c->tile_cost_host;
+		cost.assign((size_t)c->local_tiles, 0);
 		PT_HIP(c, hipMemcpyAsync(cost.data(), c->tile_cost.p, cost.size() * 2, hipMemcpyDeviceToHost, c->stream));
 		PT_HIP(c, hipStreamSynchronize(c->stream));
 		std::vector<size_t> first(1025, 0);           // counting sort: descending cost, descending index within a cost
@@ -1597,6 +1600,17 @@ int pt_debug_coop_stats(pt_ctx* c, unsigned long long* out16) {
 	PT_HIP(c, hipSetDevice(c->device));
 	PT_HIP(c, hipDeviceSynchronize());
 	return ptl::coop_stats(out16);
+}
+
+int pt_debug_tile_cost(pt_ctx* c, uint16_t* cost, int capacity, int* tiles) {
+	if(!c) return PT_ERR_ARG;
+	if(!c->prepared) return fail(c, PT_ERR_STATE, "pt_debug_tile_cost before pt_prepare");
+	if(tiles) *tiles = (int)c->tile_cost_host.size();
+	if(cost) {
+		if((size_t)capacity < c->tile_cost_host.size()) return fail(c, PT_ERR_LIMIT, "cost needs %zu entries", c->tile_cost_host.size());
+		if(!c->tile_cost_host.empty()) memcpy(cost, c->tile_cost_host.data(), c->tile_cost_host.size() * 2);
+	}
+	return PT_OK;
 }
 
 int pt_debug_grid(pt_ctx* c, uint32_t* cell_start, int cell_capacity, uint32_t* cell_items, int item_capacity, uint32_t* obj_range,

@@ -488,16 +488,51 @@ def test_determinism_and_range_at_full_size(gpu):
     assert (bits(a[520:584]) == bits(band[520:584])).all()
 
 
+def _crops_by_cost(cost, width, height, cw=32, ch=8):
+    """Where a full-size frame is compared with the oracle: 32x8 crops (four tiles side by side) at the dearest tile, the
+    cheapest tile that still casts more than its sixteen primary rays, three more of the dearest tiles of distinct tile
+    rows, the four image corners, and a whole image row through the dearest tile (as 32-pixel pieces, every fourth)."""
+    tiles_x = (width + 7) // 8
+    order = np.argsort(-cost.astype(np.int64), kind="stable")
+    crops, rows = [], set()
+
+    def add(x0, y0):
+        x0, y0 = int(min(max(0, x0), width - cw)), int(min(max(0, y0), height - ch))
+        if (x0, y0) not in crops:
+            crops.append((x0, y0))
+
+    for t in order[:64]:
+        ty, tx = divmod(int(t), tiles_x)
+        if ty not in rows and len(rows) < 4:
+            rows.add(ty)
+            add(tx * 8 - 8, ty * 8)
+    busy = np.flatnonzero(cost > 16)
+    if busy.size:
+        t = int(busy[np.argmin(cost[busy])])
+        add((t % tiles_x) * 8, (t // tiles_x) * 8)
+    for x0, y0 in ((0, 0), (width - cw, 0), (0, height - ch), (width - cw, height - ch)):
+        add(x0, y0)
+    row = (int(order[0]) // tiles_x) * 8
+    for x0 in range(0, width - cw + 1, 4 * cw):
+        add(x0, row)
+    return crops, cw, ch
+
+
 @pytest.mark.parametrize("name", ["glass-1080p-128spp-d32", "dense100k-4k-256spp-d8"])
 def test_grid_scenes_at_full_size(gpu, name):
     """The two grid-path configurations at their full sizes (49 refractive entities with depth of field at
     1080p / 128 spp / depth 32; 100 000 entities on a 64^3-hint grid at 3840x2160 / 256 spp): two runs
-    are bitwise equal, the image is finite and in [0,1], the path count is the oracle's, and a crop of
-    the full-size image matches the oracle's pixels (same sample ranges, same streams)."""
+    are bitwise equal, the image is finite and in [0,1], the path count is the oracle's, and crops of the
+    full-size image placed by the device's own cost estimate - the dearest tiles, the cheapest busy one, the
+    corners, a row through the dearest tile - match the oracle's pixels (same sample ranges, same streams):
+    bit for bit where no entity is rough (the 100 000-entity scene), within the radiance tolerance where
+    Oren-Nayar's libm calls are involved (the glass scene).  One crop is also rendered through a group of
+    eight partitions."""
     import bench
     world, objs, kw = bench.workload(name)
     st = default_settings(kw.pop("width"), kw.pop("height"), kw.pop("spp"), kw.pop("bounces"), **kw)
     gpu.prepare(world, objs, st)
+    cost = gpu.tile_cost()
     gpu.trace()
     a = gpu.download()
     gpu.trace()
@@ -515,15 +550,60 @@ def test_grid_scenes_at_full_size(gpu, name):
     good = a[~bad]
     assert good.min() >= 0 and good.max() <= 1
     assert gpu.stats().paths == sc.path_count()
-    x0, y0, w, h = st.width // 2 - 8, (st.height * 4) // 5, 16, 4          # inside the scene's content in both views
-    crop = np.zeros((st.height, st.width, 3), np.float32)
-    sc.lib.pto_render_rect(sc.h, 0, 3, x0, y0, w, h, P(crop))
+    assert cost.size == ((st.width + 7) // 8) * ((st.height + 7) // 8) and cost.max() > 16
+    crops, cw, ch = _crops_by_cost(cost, st.width, st.height)
+    assert len(crops) >= 8
+    rough_free = all(o.roughness == 0.0 for o in objs)
+    want = np.zeros((st.height, st.width, 3), np.float32)
+    beyond = values = 0
+    busy_crops = 0
+    for x0, y0 in crops:
+        sc.lib.pto_render_rect(sc.h, 0, 3, x0, y0, cw, ch, P(want))
+        got, ref = a[y0:y0 + ch, x0:x0 + cw], want[y0:y0 + ch, x0:x0 + cw]
+        busy_crops += 1 if (ref.max() > 0 and ref.min() < 1) else 0
+        fin = np.isfinite(ref).all(axis=2)
+        assert (np.isfinite(got).all(axis=2) == fin).all(), (x0, y0)
+        if rough_free:
+            assert (bits(got[fin]) == bits(ref[fin])).all(), f"crop at {x0},{y0} differs from the oracle"
+        else:
+            e = rel_err(got[fin], ref[fin])
+            beyond += int((e > REL_TOL).sum())
+            values += e.size
+            assert np.abs(got[fin].astype(np.float64) - ref[fin]).mean() < 1e-6, (x0, y0)
     sc.close()
-    got, want = a[y0:y0 + h, x0:x0 + w], crop[y0:y0 + h, x0:x0 + w]
-    assert want.max() > 0 and want.min() < 1
-    e = rel_err(got, want)
-    assert (e > REL_TOL).mean() <= 0.01, f"max rel err {e.max():.3e}"     # 192 values: Oren-Nayar libm differences only
-    assert np.abs(got.astype(np.float64) - want).mean() < 1e-6
+    assert busy_crops >= 4, "the crops must sit on the scene's content"
+    if not rough_free:
+        assert beyond <= max(1, int(EDGE_FRACTION * values) + 1), f"{beyond} of {values} values beyond the radiance tolerance"
+    # the dearest crop once more, rendered by a group of eight partitions (the multi-GPU split) on this one GPU
+    x0, y0 = crops[0]
+    g = api.Group([0] * 8)
+    whole = g.render(world, objs, st)
+    g.close()
+    assert (bits(whole[y0:y0 + ch, x0:x0 + cw]) == bits(a[y0:y0 + ch, x0:x0 + cw])).all()
+    same = bits(whole) == bits(a)
+    assert (same | ~np.isfinite(a)).all(), "the eight-partition frame differs from the one-partition frame"
+
+
+@pytest.mark.parametrize("seed", list(range(100, 110)))
+def test_cast_soak_first_scenes(gpu, seed):
+    """The first ten scenes of the longer soak run (tests/soak_cast_parity.py): random scenes, brute-force sized on even
+    seeds and grid sized on odd ones; ids, hit positions and normals of 20 000 rays against the oracle, bit for bit."""
+    small = seed % 2 == 0
+    n_obj = 3 + seed % 7 if small else 20 + (seed * 7) % 101
+    world, objs = scenes.mixed_scene(seed=seed, n=n_obj, spread=6.0 + seed % 9)
+    st = api.default_settings(64, 36, 4, 4, seed=4242, grid_hint=6 + seed % 7, brute_force_below=10)
+    gpu.prepare(world, objs, st)
+    sc = OracleScene(world, objs, st)
+    n = 20000
+    o, d = scene_rays(n, seed, objs, spread=20.0)
+    ids, pos, nrm = gpu.cast_rays(o, d)
+    rid, rpos, rnrm = np.zeros(n, np.int32), np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    sc.lib.pto_cast(sc.h, n, P(o), P(d), 0 if len(objs) < st.brute_force_below else 1, rid.ctypes.data_as(IP), P(rpos), P(rnrm))
+    sc.close()
+    hit = rid != 0
+    assert hit.mean() > 0.1
+    assert (ids == rid).all()
+    assert (bits(pos[hit]) == bits(rpos[hit])).all() and (bits(nrm[hit]) == bits(rnrm[hit])).all()
 
 
 @pytest.mark.parametrize("name", ["mixed40", "crowded", "dense2k", "dense30k", "aligned_boxes"])
