@@ -5,12 +5,17 @@
 //
 //   pt_headless [--scene default|FILE.scene] [--size WxH] [--spp N] [--bounces N] [--grid-hint N]
 //               [--seed N] [--gpus 0,1,...] [--out IMAGE.ppm] [--pfm IMAGE.pfm] [--poll-ms N]
-//               [--abort-after SECONDS] [--quiet]
+//               [--abort-after SECONDS] [--progressive FRAMES] [--bounce-histogram] [--quiet]
 //
+// --progressive FRAMES plays the interactive mode instead of one render: the scene stays resident (pt_group_prepare), every
+// frame traces one more sample per pixel into the accumulation buffers (pt_group_set_frame, pt_group_trace) and the loop
+// waits for it like a display would; the JSON line then carries the median and the 99th percentile of the frame times.
+// --bounce-histogram adds "casts_per_path": how many camera samples' paths cast 1, 2, ... rays (pt_cast_histogram).
 // With several GPUs (--gpus 0,1,...; an ordinal may repeat) the frame goes through the pt_group_* calls: every
 // entry gets a context and a round-robin share of the image's 8x8 tiles, the shares are gathered device to device
 // on the first GPU, assembled there and copied out once.  Prints one JSON line with the metrics the
 // reference shows in its stats panel (code/app.cpp:2879-2896): pixels, samples, time, plus Mpaths/s.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -25,7 +30,7 @@
 static void usage() {
 	fprintf(stderr, "usage: pt_headless [--scene default|FILE.scene] [--size WxH] [--spp N] [--bounces N] [--grid-hint N]\n"
 	                "                   [--seed N] [--gpus 0,1,...] [--out IMAGE.ppm] [--pfm IMAGE.pfm] [--poll-ms N]\n"
-	                "                   [--abort-after SECONDS] [--quiet]\n");
+	                "                   [--abort-after SECONDS] [--progressive FRAMES] [--bounce-histogram] [--quiet]\n");
 }
 
 // Screenshot encoding of the reference (code/app.cpp:1541-1547, code/rt_math.cpp:3634-3640).
@@ -42,7 +47,8 @@ int main(int argc, char** argv) {
 	pt_default_settings(&st);
 	int poll_ms = 16;
 	double abort_after = -1;
-	bool quiet = false;
+	bool quiet = false, histogram = false;
+	int progressive = 0;
 	for(int i = 1; i < argc; i++) {
 		std::string a = argv[i];
 		auto next = [&]() -> const char* { if(i + 1 >= argc) { usage(); exit(2); } return argv[++i]; };
@@ -57,6 +63,8 @@ int main(int argc, char** argv) {
 		else if(a == "--poll-ms") poll_ms = atoi(next());
 		else if(a == "--abort-after") abort_after = atof(next());
 		else if(a == "--quiet") quiet = true;
+		else if(a == "--progressive") progressive = atoi(next());
+		else if(a == "--bounce-histogram") histogram = true;
 		else if(a == "--gpus") {
 			gpus.clear();
 			std::string l = next();
@@ -83,6 +91,55 @@ int main(int argc, char** argv) {
 	pt_group* group = pt_group_create(gpus.data(), parts);
 	if(!group) { fprintf(stderr, "pt_group_create: %s\n", pt_last_error(nullptr)); return 1; }
 	std::vector<float> image((size_t)st.width * st.height * 3, 0.0f);
+
+	// the bounce histogram of the frame: a pass of its own over every partition's paths, after the render
+	auto histogram_json = [&]() -> std::string {
+		std::vector<unsigned long long> total(65, 0);
+		for(int p = 0; p < parts; p++) {
+			uint64_t h[65];
+			pt_ctx* c = pt_group_ctx(group, p);
+			if(pt_cast_histogram(c, h, 65) != PT_OK) { fprintf(stderr, "pt_cast_histogram: %s\n", pt_last_error(c)); exit(1); }
+			for(int k = 0; k < 65; k++) total[(size_t)k] += h[k];
+		}
+		int last = 64;
+		while(last > 1 && total[(size_t)last] == 0) last--;
+		std::string text = ", \"casts_per_path\": [";
+		for(int k = 1; k <= last; k++) text += (k > 1 ? ", " : "") + std::to_string(total[(size_t)k]);
+		return text + "]";
+	};
+
+	if(progressive > 0) {
+		// the interactive mode: one sample per pixel and frame, the loop waits for every frame as a display would
+		st.frame_index = 0;
+		if(pt_group_prepare(group, &world, objects.data(), (int)objects.size(), &st) != PT_OK) { fprintf(stderr, "pt_group_prepare: %s\n", pt_group_last_error(group)); return 1; }
+		std::vector<double> ms;
+		auto t_all = std::chrono::steady_clock::now();
+		for(int f = 0; f < progressive; f++) {
+			auto t_frame = std::chrono::steady_clock::now();
+			if(pt_group_set_frame(group, f) != PT_OK || pt_group_trace(group, 1) != PT_OK) { fprintf(stderr, "frame %d: %s\n", f, pt_group_last_error(group)); return 1; }
+			ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_frame).count());
+		}
+		const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_all).count();
+		if(pt_group_download(group, image.data()) != PT_OK) { fprintf(stderr, "pt_group_download: %s\n", pt_group_last_error(group)); return 1; }
+		unsigned long long paths = 0, pixels = 0;
+		for(int p = 0; p < parts; p++) { pt_stats stats; pt_get_stats(pt_group_ctx(group, p), &stats); paths += stats.paths; pixels += stats.pixels; }
+		std::vector<double> sorted = ms;
+		std::sort(sorted.begin(), sorted.end());
+		const double median = sorted[sorted.size() / 2], p99 = sorted[std::min(sorted.size() - 1, (size_t)(sorted.size() * 0.99))];
+		if(!out_pfm.empty()) {
+			FILE* f = fopen(out_pfm.c_str(), "wb");
+			if(!f) { fprintf(stderr, "cannot write %s\n", out_pfm.c_str()); return 1; }
+			fprintf(f, "PF\n%d %d\n-1.0\n", st.width, st.height);
+			for(int y = st.height - 1; y >= 0; y--) fwrite(image.data() + (size_t)y * st.width * 3, sizeof(float), (size_t)st.width * 3, f);
+			fclose(f);
+		}
+		printf("{\"scene\": \"%s\", \"mode\": \"progressive\", \"width\": %d, \"height\": %d, \"spp_wanted\": %d, \"max_bounces\": %d, \"objects\": %d, \"gpus\": %d, "
+		       "\"pixels\": %llu, \"frames\": %d, \"paths_per_frame\": %llu, \"seconds\": %.6f, \"frame_ms_median\": %.4f, \"frame_ms_p99\": %.4f, \"frame_ms_first\": %.4f%s}\n",
+		       scene.c_str(), st.width, st.height, st.spp_wanted, st.max_bounces, (int)objects.size(), parts, pixels, progressive, paths, seconds,
+		       median, p99, ms[0], histogram ? histogram_json().c_str() : "");
+		pt_group_destroy(group);
+		return 0;
+	}
 
 	auto t0 = std::chrono::steady_clock::now();
 	if(pt_group_render_start(group, &world, objects.data(), (int)objects.size(), &st, image.data()) != PT_OK) {
@@ -140,9 +197,9 @@ int main(int argc, char** argv) {
 		fclose(f);
 	}
 	printf("{\"scene\": \"%s\", \"width\": %d, \"height\": %d, \"spp_wanted\": %d, \"max_bounces\": %d, \"objects\": %d, \"gpus\": %d, "
-	       "\"pixels\": %llu, \"paths\": %llu, \"rays\": %llu, \"seconds\": %.6f, \"kernel_ms\": %.3f, \"mpaths_per_s\": %.1f, \"aborted\": %d}\n",
+	       "\"pixels\": %llu, \"paths\": %llu, \"rays\": %llu, \"seconds\": %.6f, \"kernel_ms\": %.3f, \"mpaths_per_s\": %.1f, \"aborted\": %d%s}\n",
 	       scene.c_str(), st.width, st.height, st.spp_wanted, st.max_bounces, (int)objects.size(), parts, pixels, paths, rays, seconds,
-	       kernel_ms, seconds > 0 ? paths / seconds / 1e6 : 0.0, was_aborted);
+	       kernel_ms, seconds > 0 ? paths / seconds / 1e6 : 0.0, was_aborted, histogram && !was_aborted ? histogram_json().c_str() : "");
 	pt_group_destroy(group);
 	return 0;
 }

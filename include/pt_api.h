@@ -327,6 +327,20 @@ int pt_group_render_snapshot(pt_group* group, float* rgb, uint64_t* pixels_done)
 int pt_group_render_abort(pt_group* group);
 int pt_group_render_wait(pt_group* group);
 
+/* The same work split in three for a group, for callers that keep the scene resident on every GPU and trace frame after frame
+ * (progressive display, benchmarks): the per-frame loop of the application (code/app.cpp:1436-1461) on several GPUs, driven
+ * from C.  pt_group_prepare runs every partition's pt_prepare side by side.  pt_group_trace queues one frame: every partition
+ * traces into the next of its three tile buffers and copies it, on its own stream, into the next of the root's three gathered
+ * buffers (device to device); the root lays the image out on a side stream once the copies' events have fired.  No host thread
+ * waits unless `sync` is set, so the gather and the assemble of a frame overlap the next frames' traces.  pt_group_set_frame
+ * moves every partition's progressive frame counter (a scene prepared with frame_index >= 0).  pt_group_download waits for
+ * everything queued and copies the latest frame's image to the caller. */
+int pt_group_prepare(pt_group* group, const pt_world* world, const pt_object* objects, int n_objects, const pt_settings* settings);
+int pt_group_set_frame(pt_group* group, int frame_index);
+int pt_group_trace(pt_group* group, int sync);
+int pt_group_sync(pt_group* group);
+int pt_group_download(pt_group* group, float* rgb);
+
 /* Scene files in the reference's own format (saveScene / loadScene, code/raycast.cpp:1578-1604):
  * a 224-byte World image followed by 172-byte Object images.  pt_scene_load with objects == NULL
  * only reports the object count. */

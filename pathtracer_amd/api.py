@@ -172,6 +172,11 @@ def load_core():
     lib.pt_group_render_snapshot.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
     lib.pt_group_render_abort.argtypes = [C.c_void_p]
     lib.pt_group_render_wait.argtypes = [C.c_void_p]
+    lib.pt_group_prepare.argtypes = [C.c_void_p, C.POINTER(pt_world), C.POINTER(pt_object), C.c_int, C.POINTER(pt_settings)]
+    lib.pt_group_set_frame.argtypes = [C.c_void_p, C.c_int]
+    lib.pt_group_trace.argtypes = [C.c_void_p, C.c_int]
+    lib.pt_group_sync.argtypes = [C.c_void_p]
+    lib.pt_group_download.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.pt_image_alloc.restype = C.POINTER(C.c_float)
     lib.pt_image_alloc.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.pt_image_free.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -445,6 +450,27 @@ class Group:
     def render(self, world, objs, settings, out=None):
         self.start(world, objs, settings, out)
         return self.wait()
+
+    # --- resident frames ---
+    def prepare(self, world, objs, settings):
+        self._objs = object_array(objs)
+        self._settings = settings
+        self._check(self.lib.pt_group_prepare(self.g, C.byref(world), self._objs, len(objs), C.byref(settings)), "pt_group_prepare")
+
+    def set_frame(self, frame):
+        self._check(self.lib.pt_group_set_frame(self.g, frame), "pt_group_set_frame")
+
+    def trace(self, sync=True):
+        self._check(self.lib.pt_group_trace(self.g, 1 if sync else 0), "pt_group_trace")
+
+    def sync(self):
+        self._check(self.lib.pt_group_sync(self.g), "pt_group_sync")
+
+    def download(self):
+        s = self._settings
+        out = np.zeros((s.height, s.width, 3), np.float32)
+        self._check(self.lib.pt_group_download(self.g, fptr(out)), "pt_group_download")
+        return out
 
     def part_stats(self, part):
         st = pt_stats()

@@ -123,6 +123,16 @@ struct pt_group {
 	pt_settings st{};
 	float* user_rgb = nullptr;
 	DevBuf gathered, image;              // on the root's device (part[0]): partitions side by side, the assembled image
+	// resident frames (pt_group_prepare / _trace): a ring of three tile buffers per partition (each on its partition's device)
+	// and of three gathered buffers on the root's, so that the copies and the assemble of a frame overlap the next frames' traces
+	static constexpr int kRing = 3;
+	bool prepared = false;
+	size_t stride_floats = 0;
+	uint64_t frame = 0;                  // frames queued since pt_group_prepare
+	std::vector<std::array<DevBuf, 3>> tiles;
+	DevBuf ring[3];
+	std::vector<std::array<hipEvent_t, 3>> copied;   // partition p's tiles of ring slot b have landed in the root's gathered buffer
+	hipEvent_t assembled[3] = { nullptr, nullptr, nullptr };   // the root has laid out ring slot b as the image
 	std::thread worker;
 	std::atomic<int> active{ 0 }, done{ 0 }, aborted{ 0 }, status{ 0 }, abort_requested{ 0 };
 	std::atomic<uint64_t> done_pixels{ 0 }, done_paths{ 0 };
@@ -1244,6 +1254,163 @@ void group_join(pt_group* g) {
 
 extern "C" {
 
+namespace {
+
+void group_release_ring(pt_group* g) {
+	for(size_t p = 0; p < g->tiles.size(); p++) {
+		(void)hipSetDevice(g->part[p]->device);
+		for(DevBuf& b : g->tiles[p]) b.release();
+		for(hipEvent_t& e : g->copied[p]) { if(e) (void)hipEventDestroy(e); e = nullptr; }
+	}
+	g->tiles.clear();
+	g->copied.clear();
+	if(!g->part.empty()) {
+		(void)hipSetDevice(g->part[0]->device);
+		for(DevBuf& b : g->ring) b.release();
+		for(hipEvent_t& e : g->assembled) { if(e) (void)hipEventDestroy(e); e = nullptr; }
+	}
+	g->prepared = false;
+}
+
+// Waits for every partition's stream and the root's side stream, and folds the launches' events into the statistics.
+int group_sync(pt_group* g) {
+	for(pt_ctx* c : g->part) {
+		if(hipSetDevice(c->device) != hipSuccess) return group_fail(g, PT_ERR_DEVICE, "hipSetDevice failed");
+		int rc = wait_launches(c);
+		if(rc == PT_OK) rc = collect(c);
+		if(rc != PT_OK) return group_fail(g, rc, pt_last_error(c));
+	}
+	pt_ctx* root = g->part[0];
+	if(hipSetDevice(root->device) != hipSuccess || hipStreamSynchronize(root->side) != hipSuccess) return group_fail(g, PT_ERR_DEVICE, "waiting for the root's assemble failed");
+	return PT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pt_group_prepare(pt_group* g, const pt_world* w, const pt_object* objs, int n_objects, const pt_settings* s) {
+	if(!g) return PT_ERR_ARG;
+	if(g->active.load() && !g->done.load()) return group_fail(g, PT_ERR_BUSY, "a render is active");
+	if(g->active.load()) group_join(g);
+	if(!s) return group_fail(g, PT_ERR_ARG, "null settings");
+	const int n = (int)g->part.size();
+	if(g->prepared) { int rc = group_sync(g); if(rc) return rc; }
+	group_release_ring(g);
+	for(int p = 0; p < n; p++) {
+		pt_ctx* c = g->part[(size_t)p];
+		if(c->active.load()) { if(!c->done.load()) return group_fail(g, PT_ERR_BUSY, "a partition's context is rendering on its own"); join_worker(c); }
+		pt_settings sp = *s;
+		sp.part_index = p;
+		sp.part_count = n;
+		int rc = store_inputs(c, w, objs, n_objects, &sp);
+		if(rc) return group_fail(g, rc, pt_last_error(c));
+		*c->abort_flag = 0;
+	}
+	{ std::lock_guard<std::mutex> l(g->mu); g->err.clear(); }
+	g->st = *s;
+	// every partition flattens, builds its grid and probes its tiles' cost on its own device, side by side
+	std::vector<int> rcs((size_t)n, PT_OK);
+	std::vector<std::thread> threads;
+	for(int p = 0; p < n; p++) threads.emplace_back([g, p, &rcs]() {
+		pt_ctx* c = g->part[(size_t)p];
+		rcs[(size_t)p] = hipSetDevice(c->device) == hipSuccess ? prepare(c) : fail(c, PT_ERR_DEVICE, "hipSetDevice(%d) failed", c->device);
+	});
+	for(std::thread& t : threads) t.join();
+	for(int p = 0; p < n; p++)
+		if(rcs[(size_t)p] != PT_OK) return group_fail(g, rcs[(size_t)p], "partition " + std::to_string(p) + ": " + pt_last_error(g->part[(size_t)p]));
+	size_t stride = 0;
+	for(int p = 0; p < n; p++) stride = std::max(stride, (size_t)pt_partition_tiles(s->width, s->height, p, n) * 192);
+	g->stride_floats = stride;
+	g->tiles.resize((size_t)n);
+	g->copied.resize((size_t)n);
+	for(int p = 0; p < n; p++) {
+		pt_ctx* c = g->part[(size_t)p];
+		hipError_t e = hipSetDevice(c->device);
+		for(int b = 0; b < pt_group::kRing && e == hipSuccess; b++) {
+			g->copied[(size_t)p][(size_t)b] = nullptr;
+			e = g->tiles[(size_t)p][(size_t)b].reserve(std::max<size_t>(c->fb_floats, 1) * 4);
+			if(e == hipSuccess) e = hipEventCreateWithFlags(&g->copied[(size_t)p][(size_t)b], hipEventDisableTiming);
+		}
+		if(e != hipSuccess) { group_release_ring(g); return group_fail(g, PT_ERR_DEVICE, std::string("tile buffers: ") + hipGetErrorString(e)); }
+	}
+	pt_ctx* root = g->part[0];
+	hipError_t e = hipSetDevice(root->device);
+	for(int b = 0; b < pt_group::kRing && e == hipSuccess; b++) {
+		e = g->ring[b].reserve(std::max<size_t>((size_t)n * stride, 1) * 4);
+		if(e == hipSuccess) e = hipEventCreateWithFlags(&g->assembled[b], hipEventDisableTiming);
+	}
+	if(e == hipSuccess) e = g->image.reserve((size_t)s->width * (size_t)s->height * 12);
+	if(e != hipSuccess) { group_release_ring(g); return group_fail(g, PT_ERR_DEVICE, std::string("gather buffers: ") + hipGetErrorString(e)); }
+	g->frame = 0;
+	g->prepared = true;
+	return PT_OK;
+}
+
+int pt_group_set_frame(pt_group* g, int frame_index) {
+	if(!g) return PT_ERR_ARG;
+	if(!g->prepared) return group_fail(g, PT_ERR_STATE, "pt_group_set_frame before pt_group_prepare");
+	for(pt_ctx* c : g->part) {
+		int rc = pt_set_frame(c, frame_index);
+		if(rc) return group_fail(g, rc, pt_last_error(c));
+	}
+	return PT_OK;
+}
+
+// One frame of the prepared scene.  Ring slot b = frame % 3: every partition traces into its tile buffer b and copies it, on
+// its own stream, straight into the root's gathered buffer b (a peer copy: over xGMI between different GPUs, every partition on
+// its own link); the root's side stream waits for the copies' events and lays the image out.  Nothing waits on the host: a
+// partition's stream only waits, from the fourth frame on, for the assemble that read gathered buffer b three frames ago.
+int pt_group_trace(pt_group* g, int sync) {
+	if(!g) return PT_ERR_ARG;
+	if(!g->prepared) return group_fail(g, PT_ERR_STATE, "pt_group_trace before pt_group_prepare");
+	if(g->active.load() && !g->done.load()) return group_fail(g, PT_ERR_BUSY, "a render is active");
+	const int n = (int)g->part.size();
+	const int b = (int)(g->frame % pt_group::kRing);
+	pt_ctx* root = g->part[0];
+	for(int p = 0; p < n; p++) {
+		pt_ctx* c = g->part[(size_t)p];
+		if(hipSetDevice(c->device) != hipSuccess) return group_fail(g, PT_ERR_DEVICE, "hipSetDevice failed");
+		if(g->frame >= (uint64_t)pt_group::kRing && hipStreamWaitEvent(c->stream, g->assembled[b], 0) != hipSuccess) return group_fail(g, PT_ERR_DEVICE, "hipStreamWaitEvent failed");
+		*c->abort_flag = 0;
+		int rc = trace(c, g->tiles[(size_t)p][(size_t)b].as<float>(), nullptr, false, false);
+		if(rc != PT_OK) return group_fail(g, rc, pt_last_error(c));
+		hipError_t e = hipSuccess;
+		// (a group of one renders the whole image row by row: its buffer is the image, there is nothing to lay out)
+		float* to = n == 1 ? g->image.as<float>() : g->ring[b].as<float>() + (size_t)p * g->stride_floats;
+		if(c->fb_floats > 0) e = hipMemcpyPeerAsync(to, root->device, g->tiles[(size_t)p][(size_t)b].p, c->device, c->fb_floats * 4, c->stream);
+		if(e == hipSuccess) e = hipEventRecord(g->copied[(size_t)p][(size_t)b], c->stream);
+		if(e != hipSuccess) return group_fail(g, PT_ERR_DEVICE, std::string("gathering a partition: ") + hipGetErrorString(e));
+	}
+	if(hipSetDevice(root->device) != hipSuccess) return group_fail(g, PT_ERR_DEVICE, "hipSetDevice failed");
+	for(int p = 0; p < n; p++)
+		if(hipStreamWaitEvent(root->side, g->copied[(size_t)p][(size_t)b], 0) != hipSuccess) return group_fail(g, PT_ERR_DEVICE, "hipStreamWaitEvent failed");
+	if(n > 1 && ptl::launch_assemble(g->ring[b].as<float>(), g->stride_floats, n, g->st.width, g->st.height, g->image.as<float>(), root->side) != hipSuccess)
+		return group_fail(g, PT_ERR_DEVICE, "pt_k_assemble launch failed");
+	if(hipEventRecord(g->assembled[b], root->side) != hipSuccess) return group_fail(g, PT_ERR_DEVICE, "hipEventRecord failed");
+	g->frame++;
+	return sync ? group_sync(g) : PT_OK;
+}
+
+int pt_group_sync(pt_group* g) {
+	if(!g) return PT_ERR_ARG;
+	if(!g->prepared) return group_fail(g, PT_ERR_STATE, "pt_group_sync before pt_group_prepare");
+	return group_sync(g);
+}
+
+int pt_group_download(pt_group* g, float* rgb) {
+	if(!g) return PT_ERR_ARG;
+	if(!rgb) return group_fail(g, PT_ERR_ARG, "null output");
+	if(!g->prepared || g->frame == 0) return group_fail(g, PT_ERR_STATE, "pt_group_download before a frame was traced");
+	int rc = group_sync(g);
+	if(rc) return rc;
+	pt_ctx* root = g->part[0];
+	if((rc = download_image(root, g->image.p, (size_t)g->st.width * (size_t)g->st.height * 12, rgb)) != PT_OK) return group_fail(g, rc, pt_last_error(root));
+	return PT_OK;
+}
+
+}  // extern "C"
+
 pt_group* pt_group_create(const int* devices, int n) {
 	if(!devices || n < 1 || n > 64) { fail(nullptr, PT_ERR_ARG, "pt_group_create: 1..64 devices"); return nullptr; }
 	pt_group* g = new pt_group();
@@ -1269,6 +1436,8 @@ pt_group* pt_group_create(const int* devices, int n) {
 void pt_group_destroy(pt_group* g) {
 	if(!g) return;
 	if(g->active.load()) { pt_group_render_abort(g); group_join(g); }
+	if(g->prepared) (void)group_sync(g);
+	group_release_ring(g);
 	if(!g->part.empty()) {
 		(void)hipSetDevice(g->part[0]->device);
 		g->gathered.release();

@@ -1,4 +1,8 @@
-"""Diagnostic: event counters of the wave-cooperative cast (needs a library built with -DPT_COOP_STATS)."""
+"""Diagnostic: counters of the wave-cooperative cast.  Needs a library built with -DPT_COOP_STATS (event counts) or
+-DPT_COOP_TIMING (cycles per phase, summed over wavefronts; add -DPT_COOP_TIMING_WAITS for the exposed memory waits);
+the two builds use the same sixteen slots for different things, and this script tells them apart by slot 0 (the
+kernel's wave cycles, which only a timing build fills).
+usage: PT_CORE_LIB=pathtracer_amd/variant_<name>.so python profiles/coop_stats.py [workload] [waits]"""
 import ctypes as C
 import os
 import sys
@@ -8,31 +12,41 @@ import bench  # noqa: E402
 from pathtracer_amd import api  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "glass-1080p-16spp-d32"
+waits_build = len(sys.argv) > 2 and sys.argv[2] == "waits"
 world, objs, kw = bench.workload(name)
 st = api.default_settings(kw.pop("width"), kw.pop("height"), kw.pop("spp"), kw.pop("bounces"), **kw)
 r = api.Renderer(0)
 r.prepare(world, objs, st)
 buf = (C.c_ulonglong * 16)()
 r.lib.pt_debug_coop_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
-r.lib.pt_debug_coop_stats(r.ctx, buf)
+if r.lib.pt_debug_coop_stats(r.ctx, buf) != 16:
+    raise SystemExit("this library is a normal build: no counters (build with -DPT_COOP_STATS or -DPT_COOP_TIMING)")
 r.trace()
 r.lib.pt_debug_coop_stats(r.ctx, buf)
 s = r.stats()
-names = ["", "segments", "chunks", "tests", "cells", "items", "deduped", "sphere_rejected", "accepted", "wave_casts"]
 casts = s.rays
-print(name, "casts", casts, "kernel_ms %.2f" % s.trace_ms)
-names += ["cyc_walk|handout", "cyc_expand|camera", "cyc_drain|shade", "cyc_verdict", "cyc_cast", "cyc_generate_shade"]
-print("  wave cycles total %d" % buf[0])
-if buf[5]:
-    span = (buf[4] - buf[3]) / 100.0
-    print("  waves %d  kernel span %.1f us  mean wave busy %.1f us  = %.1f %% of the span" % (buf[5], span, buf[2] / buf[5] / 100.0, buf[2] / buf[5] / (buf[4] - buf[3]) * 100))
-tn = {2: "chunk_fetch", 3: "chunk_intersect", 4: "chunk_cellsearch", 5: "chunk_writeback"}
-for i in range(2, 6):
-    print(f"  {tn[i]:20s} {buf[i]:14d}  {100.0 * buf[i] / max(1, buf[0]):5.1f} % of wave time   per segment {buf[i] / max(1, buf[1]):8.0f}")
-print("  chunks direct/ellipsoid/cyl+cone/mixed", buf[6], buf[7], buf[8], buf[9])
-print("  (a -DPT_COOP_TIMING_WAITS build keeps cycles in those four instead: walk until its loads are issued %.1f %%, wait for them %.1f %%,"
-      " wait for list entries %.1f %%, wait for a chunk's first records %.1f %% of wave time)" % tuple(100.0 * buf[i] / max(1, buf[0]) for i in (6, 7, 8, 9)))
-for i in range(10, 16):
-    print(f"  {names[i]:20s} {buf[i]:14d}  {100.0 * buf[i] / max(1, buf[0]):5.1f} % of wave time   per segment {buf[i] / max(1, buf[1]):8.0f}")
-for i in range(1, 10):
-    print(f"  {names[i]:16s} {buf[i]:12d}   per wave-cast {buf[i] / max(1, buf[9]):8.2f}   per lane-cast {buf[i] / max(1, casts):7.3f}")
+print(f"{name}: {s.paths} paths, {casts} ray casts, kernel {s.dominant_kernel_ms:.2f} ms")
+if buf[0] == 0:
+    # event counts
+    labels = {1: "segments", 2: "chunks", 3: "exact tests", 4: "cells recorded", 5: "list entries read", 6: "  of them repeats (listed in the cell before)",
+              7: "  of them rejected by the sphere filter", 8: "hits inside a recorded cell", 9: "calls of the cast with walking lanes"}
+    calls = max(1, buf[9])
+    print(f"{'event':46s} {'count':>14s} {'per call':>10s} {'per ray':>9s}")
+    for i in range(1, 10):
+        print(f"{labels[i]:46s} {buf[i]:14d} {buf[i] / calls:10.2f} {buf[i] / max(1, casts):9.3f}")
+    print(f"lanes with a new ray per call: {casts / calls:.1f} of 64; candidates per chunk: {buf[3] / max(1, buf[2]):.1f} of 64")
+else:
+    total = buf[0]
+    print(f"wave cycles, all wavefronts: {total}; segments {buf[1]}")
+    rows = [(10, "walk (probe steps, list bounds, descriptors)"), (11, "expand (list entries -> candidates)"), (12, "drain (chunks of exact tests)"),
+            (13, "verdict"), (14, "cast, all of the above"), (15, "hand-out, camera ray, shade, range sums")]
+    for i, label in rows:
+        print(f"  {label:50s} {100.0 * buf[i] / total:5.1f} % of wave time   {buf[i] / max(1, buf[1]):9.0f} cycles per segment")
+    print("  inside the chunks:")
+    for i, label in ((2, "fetch candidate and ray"), (3, "exact intersection"), (4, "search for the hit's cell, key"), (5, "rendezvous and write-back")):
+        print(f"    {label:48s} {100.0 * buf[i] / total:5.1f} % of wave time")
+    if waits_build:
+        for i, label in ((6, "walk until its loads are issued"), (7, "wait for the list bounds"), (8, "wait for the list entries"), (9, "wait for a chunk's first records")):
+            print(f"  {label:50s} {100.0 * buf[i] / total:5.1f} % of wave time")
+    else:
+        print(f"  chunks run: direct kinds {buf[6]}, ellipsoid {buf[7]}, cylinder / cone {buf[8]}, mixed {buf[9]}")

@@ -378,6 +378,62 @@ def test_pipelined_partition_frames(gpu):
     assert (bits(last) == bits(want[-1])).all()
 
 
+@pytest.mark.parametrize("parts", [1, 3])
+def test_group_resident_progressive_frames(gpu, parts):
+    """pt_group_prepare / _set_frame / _trace / _download: the application's frame loop on several partitions, driven from C.
+    Twelve progressive frames queued without a host synchronisation in between (ring of three tile and gathered buffers,
+    copies on the partitions' streams, assemble on the root's side stream); every frame's image differs from the one
+    before, so a copy that read a tile buffer too early or a trace that overwrote it too soon would show.  Frames
+    downloaded on the way (after 1, 2, 5 and 12 frames) and the last one must equal the same frames of an unpartitioned context."""
+    world, objs = scenes.mixed_scene(seed=7, n=40)
+    w, h, frames = 200, 120, 12
+    gpu.prepare(world, objs, settings_for("mixed40", w, h, 8, 8, frame_index=0))
+    want = []
+    for f in range(frames):
+        gpu.set_frame(f)
+        gpu.trace()
+        want.append(gpu.download())
+    assert not (bits(want[3]) == bits(want[4])).all()
+    g = api.Group([0] * parts)
+    with pytest.raises(api.PtError, match="before pt_group_prepare"):
+        g.trace()
+    g.prepare(world, objs, settings_for("mixed40", w, h, 8, 8, frame_index=0))
+    for f in range(frames):
+        g.set_frame(f)
+        g.trace(sync=False)
+        if f in (0, 1, 4):
+            assert (bits(g.download()) == bits(want[f])).all(), f
+    assert (bits(g.download()) == bits(want[frames - 1])).all()
+    # a full render through the same group afterwards, then resident frames again: the two interfaces do not disturb each other
+    st = settings_for("mixed40", w, h, 16, 8)
+    whole = gpu.render(world, objs, st)
+    assert (bits(g.render(world, objs, st)) == bits(whole)).all()
+    g.prepare(world, objs, st)
+    g.trace()
+    assert (bits(g.download()) == bits(whole)).all()
+    stats = [g.part_stats(p) for p in range(parts)]
+    assert sum(s.paths for s in stats) == gpu.stats().paths
+    g.close()
+
+
+def test_group_on_two_devices_when_there_are_two(gpu):
+    """The group path across different GPUs (peer copies over xGMI, peer access, per-device static data): runs only where the
+    box has two devices, so that the first multi-GPU machine this suite meets pins it."""
+    torch = pytest.importorskip("torch")
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU here")
+    world, objs = scenes.mixed_scene(seed=7, n=40)
+    st = settings_for("mixed40", 200, 117, 16, 8)
+    whole = gpu.render(world, objs, st)
+    g = api.Group([0, 1])
+    assert (bits(g.render(world, objs, st)) == bits(whole)).all()
+    g.prepare(world, objs, st)
+    for _ in range(4):
+        g.trace(sync=False)
+    assert (bits(g.download()) == bits(whole)).all()
+    g.close()
+
+
 @pytest.mark.parametrize("parts", [1, 2, 5])
 def test_group_render_gathers_on_the_device(gpu, parts):
     """pt_group_*: one frame split over several contexts of one process (here all on the one GPU), partitions copied
@@ -455,6 +511,26 @@ def test_headless_harness(gpu, tmp_path):
     raw = open(pfm, "rb").read()
     got = np.frombuffer(raw[-160 * 90 * 12:], np.float32).reshape(90, 160, 3)[::-1]
     assert (bits(got) == bits(want)).all()
+    # the bounce histogram of the same frame: its bins add up to the paths and, weighted, to the rays
+    r = subprocess.run([exe, "--scene", scene_file, "--size", "160x90", "--spp", "16", "--bounces", "8", "--seed", "4242",
+                        "--gpus", "0,0", "--bounce-histogram", "--quiet"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    hist = info["casts_per_path"]
+    assert sum(hist) == info["paths"] and sum((k + 1) * v for k, v in enumerate(hist)) == info["rays"] and len(hist) <= 8
+    # the interactive mode on three partitions: twenty progressive frames from C, latency figures, and the accumulated image
+    r = subprocess.run([exe, "--scene", scene_file, "--size", "160x90", "--spp", "16", "--bounces", "8", "--seed", "4242",
+                        "--gpus", "0,0,0", "--progressive", "20", "--pfm", pfm, "--quiet"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["mode"] == "progressive" and info["frames"] == 20 and 0 < info["frame_ms_median"] <= info["frame_ms_p99"]
+    gpu.prepare(world, objs, settings_for("mixed40", 160, 90, 16, 8, frame_index=0))
+    for f in range(20):
+        gpu.set_frame(f)
+        gpu.trace()
+    raw = open(pfm, "rb").read()
+    got = np.frombuffer(raw[-160 * 90 * 12:], np.float32).reshape(90, 160, 3)[::-1]
+    assert (bits(got) == bits(gpu.download())).all()
     # abort path: a long render stopped from the frame loop still ends cleanly
     r = subprocess.run([exe, "--scene", scene_file, "--size", "1920x1080", "--spp", "256", "--bounces", "32", "--abort-after", "0.02",
                         "--poll-ms", "2", "--quiet"], capture_output=True, text=True, timeout=120)
