@@ -299,6 +299,47 @@ def measure(env, name, steps, warmup, prewarm_enabled=True, ranges=0):
             "dt": env.max_over_ranks(dt), "paths": env.max_over_ranks(stats.paths, "sum"), "kernel_ms": env.max_over_ranks(kstats.dominant_kernel_ms)}
 
 
+def progressive_block(env, frames=256, warm=32):
+    """Configuration 5, the interactive mode: the demo scene at 1080p, one sample per pixel and frame added into the
+    accumulation buffer, every frame waited for as a display would (the per-frame latency a viewer sees): median and 99th
+    percentile over `frames` frames.  With one rank the frame is pt_set_frame + pt_trace with synchronisation; with
+    several, every rank traces its tiles, the tile buffers are gathered on rank 0 and assembled there (one pipeline step
+    and a device synchronisation on every rank), and the latency reported is the slowest rank's."""
+    torch, world_size, rank = env.torch, env.world_size, env.rank
+    world, objs, kw = workload("demo-1080p-progressive")
+    skw = dict(kw)
+    st = api.default_settings(skw.pop("width"), skw.pop("height"), skw.pop("spp"), skw.pop("bounces"),
+                              part_index=rank, part_count=world_size, **skw)
+    r = api.Renderer(env.local_rank)
+    r.prepare(world, objs, st)
+    if world_size > 1:
+        pipe = ptdist.FramePipeline([r], [rank], world_size, st.width, st.height, rank, world_size)
+
+        def frame(f):
+            r.set_frame(f)
+            pipe.step()
+            torch.cuda.synchronize()
+    else:
+        def frame(f):
+            r.set_frame(f)
+            r.trace()                        # synchronises
+    for f in range(warm):
+        frame(f)
+    lat = np.zeros(frames)
+    for f in range(frames):
+        t0 = time.perf_counter()
+        frame(f)
+        lat[f] = (time.perf_counter() - t0) * 1e3
+    r.sync()
+    paths = env.max_over_ranks(r.stats().paths, "sum")
+    kernel_ms = env.max_over_ranks(r.stats().dominant_kernel_ms)
+    med, p99, worst = (env.max_over_ranks(v) for v in (np.median(lat), np.percentile(lat, 99), lat.max()))
+    r.close()
+    return {"workload": "demo-1080p-progressive", "definition": "one sample per pixel per frame, every frame waited for; host clock around the frame",
+            "frames": frames, "warmup_frames": warm, "median_ms": med, "p99_ms": p99, "max_ms": worst, "kernel_ms": kernel_ms,
+            "paths_per_frame": int(paths), "n_gpus": world_size}
+
+
 def measured_traffic(name, world_size):
     """HBM bytes per launch of the trace kernel from the committed counter passes (profiles/summarise.py), or None."""
     try:
@@ -326,9 +367,16 @@ def roofline_block(name, m, world_size, flops_per_path=None):
         roof["frac"] = roof["achieved"] / PEAK_FP32_VALU_TFLOPS
         roof["frac_of_scalar_issue_peak"] = roof["achieved"] / PEAK_SCALAR_ISSUE_TFLOPS
     traffic, source = measured_traffic(name, world_size)
+    # what the path has to write, whatever the design: twelve bytes a pixel (code/raycast.cpp:1270).  The design writes one
+    # 16-byte range sum per pixel and range instead and folds them in a second kernel; traffic_ratio says what that costs.
+    algorithmic = 12 * int(k.pixels) if world_size == 1 else None         # (the committed counter passes are one-GPU runs)
+    if algorithmic:
+        roof["algorithmic_bytes"] = algorithmic
     if traffic is not None:
         roof["traffic"] = traffic
         roof["traffic_source"] = source
+        if algorithmic:
+            roof["traffic_ratio"] = traffic / algorithmic
     return roof
 
 
@@ -340,7 +388,7 @@ def main():
     ap.add_argument("--workload", default="demo-1080p-64spp-d8")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed steps that bring an idle GPU up to its clocks")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the two grid-scene configurations that follow the default workload")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the two grid-scene configurations and the progressive frames that follow the default workload")
     ap.add_argument("--ranges", type=int, default=0, help="pt_settings.sample_ranges (0 = the library's choice)")
     args = ap.parse_args()
 
@@ -381,9 +429,11 @@ def main():
     # glass scene (1080p, 128 spp, depth 32, lens) and the 100 000-entity scene (3840x2160, 256 spp) - the frame that
     # is long enough to scale over eight GPUs.  Only after the default workload; every rank takes part.
     secondary = []
+    progressive = None
     if args.workload == "demo-1080p-64spp-d8" and not args.no_secondary:
         r.close()
         r = None
+        progressive = progressive_block(env)
         for name, k_steps, k_warm in (("glass-1080p-128spp-d32", 10, 2), ("dense100k-4k-256spp-d8", 3, 1)):
             mm = measure(env, name, k_steps, k_warm, False, 0)
             secondary.append({"workload": name, "steps": k_steps, "warmup": k_warm, "ms_per_step": mm["dt"] / k_steps * 1e3,
@@ -416,9 +466,12 @@ def main():
             out["end_to_end"] = end_to_end
         if secondary:
             out["secondary"] = secondary
-        # algorithmic HBM bytes of the trace kernel: one 16-byte range sum per pixel and range, written once
-        # (pt_k_resolve then reads them and writes the 12-byte pixels)
-        out["hbm_algorithmic_bytes_per_launch"] = int(16 * stats.pixels * api.load_core().pt_sample_ranges(C.byref(st)))
+        if progressive is not None:
+            out["progressive"] = progressive
+        # HBM bytes per launch: what the path writes by definition (12 bytes a pixel), and what this design's trace kernel
+        # writes (one 16-byte range sum per pixel and range; pt_k_resolve then reads them and writes the pixels)
+        out["hbm_algorithmic_bytes_per_launch"] = int(12 * stats.pixels)
+        out["hbm_design_bytes_per_launch"] = int(16 * stats.pixels * api.load_core().pt_sample_ranges(C.byref(st)))
         print(json.dumps(out), flush=True)
     if r is not None:
         r.close()

@@ -151,6 +151,17 @@ def test_bench_workloads_and_cpu_leg():
     world, objs, _ = bench.workload("demo-640x360-16spp-d8")
     row = bench.cpu_c1(world, objs, 2)
     assert row["paths"] > 0 and row["seconds_1_threads"] > 0 and row["mpaths_per_s_2_threads"] > 0
+    # the roofline block of the driver's line: achieved rate against the vector peak, and the measured bytes against the
+    # twelve bytes a pixel the path has to write
+    from pathtracer_amd.api import pt_stats
+    k = pt_stats()
+    k.pixels, k.trace_ms_min, k.trace_ms_max = 1920 * 1080, 1.6, 1.7
+    roof = bench.roofline_block("demo-1080p-64spp-d8", {"kstats": k, "kernel_ms": 1.65, "paths": 139622400}, 1)
+    assert roof["bound"] == "valu" and roof["peak"] == bench.PEAK_FP32_VALU_TFLOPS and 0 < roof["frac"] < 1
+    assert roof["algorithmic_bytes"] == 12 * 1920 * 1080
+    if roof["traffic"] is not None:
+        assert roof["traffic_ratio"] == pytest.approx(roof["traffic"] / roof["algorithmic_bytes"])
+    assert callable(bench.progressive_block)
     counters = {k: 1 for k in list(bench.FLOP_WEIGHTS) + ["uneven_sphere"]}
     assert bench.flops_from_counters(counters) == sum(v for k, v in bench.FLOP_WEIGHTS.items() if k != "unit_space") + 3 * bench.FLOP_WEIGHTS["unit_space"]
 
