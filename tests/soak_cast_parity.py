@@ -1,6 +1,6 @@
 """A longer run of the ray-cast comparison than the test suite holds: many random scenes, brute-force sized (3 to 9 entities,
 every ray tests every entity) and grid sized (20 to 120 entities), ids, hit positions and normals of the device against the
-oracle bit for bit.  Not collected by pytest; run on the GPU box:  python tests/soak_cast_parity.py [first_seed] [scenes]"""
+oracle bit for bit.  From seed 1000 on every fourth scene also holds one to three planes (code/raycast.cpp:885-889, 937-955).  Not collected by pytest; run on the GPU box:  python tests/soak_cast_parity.py [first_seed] [scenes]"""
 import ctypes as C
 import os
 import sys
@@ -16,6 +16,23 @@ from rayutil import scene_rays  # noqa: E402
 
 P = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
 IP = C.POINTER(C.c_int32)
+
+
+def with_planes(objs, seed):
+    """Seeds from 1000 on, every fourth: one to three planes at random places of the entity list, tilted at random."""
+    if seed < 1000 or seed % 4 != 3:
+        return objs
+    rng = np.random.default_rng(seed)
+    objs = list(objs)
+    for _ in range(1 + seed % 3):
+        axis = rng.normal(size=3)
+        rot = scenes._axis_quat(tuple(axis / np.linalg.norm(axis)), float(rng.uniform(0, 180)))
+        pos = tuple(rng.uniform(-12, 12, size=3))
+        plane = api.make_object(pos, (1, 1, 1), api.PT_GEOM_PLANE, rot=rot, color=tuple(rng.uniform(0.2, 0.9, size=3)), refl=float(rng.choice([0.0, 0.5, 1.0])))
+        objs.insert(int(rng.integers(0, len(objs) + 1)), plane)
+    return objs
+
+
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 gpu = api.Renderer(0)
@@ -24,6 +41,7 @@ for seed in range(first, first + count):
     small = seed % 2 == 0
     n_obj = 3 + seed % 7 if small else 20 + (seed * 7) % 101
     world, objs = scenes.mixed_scene(seed=seed, n=n_obj, spread=6.0 + seed % 9)
+    objs = with_planes(objs, seed)
     st = api.default_settings(64, 36, 4, 4, seed=4242, grid_hint=6 + seed % 7, brute_force_below=10)
     gpu.prepare(world, objs, st)
     sc = OracleScene(world, objs, st)
@@ -44,6 +62,7 @@ bad_images = 0
 for seed in range(first, first + count // 2):
     n_obj = 3 + seed % 7 if seed % 2 == 0 else 20 + (seed * 5) % 60
     world, objs = scenes.mixed_scene(seed=seed, n=n_obj, rough_share=0.0, spread=6.0 + seed % 9)
+    objs = with_planes(objs, seed)
     st = api.default_settings(96, 54, 8, 4 + 4 * (seed % 3), seed=seed, grid_hint=6 + seed % 7, brute_force_below=10)
     img = gpu.render(world, objs, st)
     sc = OracleScene(world, objs, st)
