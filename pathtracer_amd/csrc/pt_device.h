@@ -1113,6 +1113,13 @@ PT_DEV void coop_drain(const Scene& sc, CoopShared& sh, int lane) {
 PT_MARK("drain_begin");
 	const uint32_t total = uniform(sh.count[KIND_COUNT]);
 	if(total == 0) return;
+#ifdef PT_COOP_STATS
+	if(lane == 0) {
+		if(total > 64u && total <= 80u) PT_STAT(14, 1);                     // a second chunk for at most 16 candidates
+		if(total > 128u && total <= 144u) PT_STAT(14, 1);
+		if(total <= 32u) PT_STAT(15, 1);                                    // one chunk less than half full
+	}
+#endif
 	if(total <= 64u) {
 		// one chunk of mixed kinds, whatever their order: straight from the pool
 		coop_chunk<KIND_MIXED, FEAT>(sc, sh, sh.pool, 0, total, lane);
@@ -1311,6 +1318,14 @@ PT_MARK("walk_dealt");
 		}
 		const bool turned_away = turned_at < COOP_CELLS;
 		const int recorded = imin(m, turned_at);
+#ifdef PT_COOP_STATS
+		if(walking) {
+			PT_STAT(10, 1);
+			if(my_lists == 0 && more) PT_STAT(11, 1);                       // nothing to collect in the whole segment, and the ray goes on
+			if(my_lists == 0 && !more) PT_STAT(12, 1);                      // nothing to collect, and the ray leaves the grid
+			if(my_lists == 1) PT_STAT(13, 1);
+		}
+#endif
 PT_MARK("walk_placed");
 		// the first refusal in serving order ends the sequence: what was placed before it is contiguous from zero
 		uint32_t ndesc = all_lists, total = all_entries;

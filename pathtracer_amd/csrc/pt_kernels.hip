@@ -67,6 +67,12 @@ enum { CAST_BRUTE = 0, CAST_GRID_LANE = 1, CAST_GRID_COOP = 2 };
 // unrotated boxes with opaque, smooth materials - the reference's demo scene is one - runs a variant without the
 // unit-space intersectors, Fresnel and Oren-Nayar code, which fits five wavefronts per SIMD instead of four; the
 // frame is bound by each wavefront's own instruction latencies, so the fifth wavefront is worth 13 %.
+// WAVES_SIX (brute-force variants, beside the FEAT bits): the same code compiled for six wavefronts per SIMD (80 registers).
+// On a long frame the sixth wavefront is worth 3 % although twenty cold values of the lean variant then live in scratch
+// memory; the all-features variant, which would spill 36, parks its cold lane state in LDS instead (kCold in the kernel) and
+// gains as much.  A short launch - a progressive frame, an eighth of a frame - loses with it (more wavefronts to start and to
+// feed from the same counters: +14 % on a one-sample frame), so the launch picks by the work there is (launch_trace).
+enum { WAVES_SIX = 16 };
 #ifndef PT_PLAIN_WAVES_PER_SIMD
 #define PT_PLAIN_WAVES_PER_SIMD 5
 #endif
@@ -79,8 +85,9 @@ enum { CAST_BRUTE = 0, CAST_GRID_LANE = 1, CAST_GRID_COOP = 2 };
 
 // The trace kernel has a name other units can see: its brute-force variants are compiled as a unit of their own (below).
 namespace ptk {
-template <int MODE, int FEAT, bool THROUGH>
-__global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIMD : FEAT == 0 ? PT_PLAIN_WAVES_PER_SIMD : PT_BRUTE_WAVES_PER_SIMD) void pt_k_trace(ptl::TraceJob job) {
+template <int MODE, int VARIANT, bool THROUGH>
+__global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIMD : (VARIANT & WAVES_SIX) ? 6 : (VARIANT & FEAT_EVERY) == 0 ? PT_PLAIN_WAVES_PER_SIMD : PT_BRUTE_WAVES_PER_SIMD) void pt_k_trace(ptl::TraceJob job) {
+	constexpr int FEAT = VARIANT & FEAT_EVERY;
 #ifdef PT_COOP_TIMING
 	constexpr bool kWaveLds = true;           // the phase timers live in the per-wave LDS block
 #else
@@ -114,6 +121,14 @@ __global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIM
 	uint4* const stage_a = staged + (kStaged ? (threadIdx.x / 64) * 128 : 0);
 	uint4* const stage_b = stage_a + (kStaged ? 64 : 0);
 	size_t tile_item0 = 0;                     // first range sum of the staged group's range
+	// Cold lane state in LDS (the all-features variant at six wavefronts): what a lane needs once per sample or once per
+	// item - table indices, pixel centre, pixel, the running range sum, where it goes - waits in LDS, a word of all 256
+	// lanes side by side, instead of in fifteen registers that are live across the cast.  (For the lean variant the same
+	// parking measured no better than the compiler's own spills, and worse at five wavefronts: +4 %.)
+	constexpr bool kCold = MODE == CAST_BRUTE && (VARIANT & WAVES_SIX) != 0 && FEAT != 0;
+	enum { C_BASE = 0, C_END, C_LENS, C_PASS, C_OX, C_OY, C_OZ, C_ITEM_LO, C_ITEM_HI, C_PXY, C_SX, C_SY, C_SZ, C_WORDS };
+	__shared__ uint32_t cold_raw[kCold ? C_WORDS * kBlock : 1];
+	uint32_t* const cold = cold_raw + (kCold ? threadIdx.x : 0);
 	bool dry = false;
 	uint32_t shard = blockIdx.x % kShards;     // lane 0's view is the one that counts
 
@@ -227,12 +242,23 @@ PT_MARK("loop_begin");
 					const uint4 a = stage_a[j];
 					if(a.y != 0u) {                                  // else: outside the image or nothing to trace - the lane asks again
 						const uint4 b = stage_b[j];
-						px = tile_x0 + (j & 7);
-						py = tile_y0 + (j >> 3);
-						sample_base = (int)a.x; si = (int)(a.y & 0xffffu); si_end = (int)(a.y >> 16); lens = (int)a.z; pass = a.w;
-						origin = v3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
-						item = tile_item0 + b.w;
-						sum = v3(0, 0, 0);
+						si = (int)(a.y & 0xffffu);
+						if(kCold) {
+							const size_t it = tile_item0 + b.w;
+							cold[C_END * kBlock] = a.y >> 16; cold[C_PASS * kBlock] = a.w;
+							cold[C_ITEM_LO * kBlock] = (uint32_t)it; cold[C_ITEM_HI * kBlock] = (uint32_t)((unsigned long long)it >> 32);
+							cold[C_PXY * kBlock] = (uint32_t)(tile_x0 + (j & 7)) | ((uint32_t)(tile_y0 + (j >> 3)) << 16);
+							cold[C_BASE * kBlock] = a.x; cold[C_LENS * kBlock] = a.z;
+							cold[C_OX * kBlock] = b.x; cold[C_OY * kBlock] = b.y; cold[C_OZ * kBlock] = b.z;
+							cold[C_SX * kBlock] = 0u; cold[C_SY * kBlock] = 0u; cold[C_SZ * kBlock] = 0u;
+						} else {
+							px = tile_x0 + (j & 7);
+							py = tile_y0 + (j >> 3);
+							sample_base = (int)a.x; si_end = (int)(a.y >> 16); lens = (int)a.z; pass = a.w;
+							origin = v3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+							item = tile_item0 + b.w;
+							sum = v3(0, 0, 0);
+						}
 						state = NEED_PATH;
 					}
 				}
@@ -279,10 +305,13 @@ PT_MARK("handed_out");
 PT_MARK("camera_begin");
 		// ---- stage 1: generate the camera ray of the next sample (code/raycast.cpp:1059-1090) ---
 		if(state == NEED_PATH) {
-			v2f s = sc.samples[sample_base + si];
+			const int table_at = kCold ? (int)cold[C_BASE * kBlock] : sample_base;
+			const int lens_at = kCold ? (int)cold[C_LENS * kBlock] : lens;
+			v2f s = sc.samples[table_at + si];
 			// the cooperative cast is short of registers: it recomputes what the other variants keep per pixel
-			const V3 from = MODE == CAST_GRID_COOP ? pixel_origin_tab(job, fr, px, py) : origin;
-			camera_ray(sc, fr, from, s, lens + si, rp, rd);
+			const V3 from = MODE == CAST_GRID_COOP ? pixel_origin_tab(job, fr, px, py)
+			              : kCold ? v3(__uint_as_float(cold[C_OX * kBlock]), __uint_as_float(cold[C_OY * kBlock]), __uint_as_float(cold[C_OZ * kBlock])) : origin;
+			camera_ray(sc, fr, from, s, lens_at + si, rp, rd);
 #ifdef PT_EAGER_SEED
 			sample_stream(fr, px, py, si, (uint64_t)pass, rng);
 #endif
@@ -321,17 +350,34 @@ PT_MARK("cast_end");
 #ifndef PT_EAGER_SEED
 			// The sample's random stream is set up when its path first lands on an entity: a path that leaves into the sky
 			// draws no number (nearly half the paths of the demo frame), and nothing between the camera and this point draws one.
-			if(id != 0 && bounce == 0) sample_stream(fr, px, py, si, (uint64_t)pass, rng);
+			if(id != 0 && bounce == 0) {
+				if(kCold) {
+					const uint32_t pxy = cold[C_PXY * kBlock];
+					sample_stream(fr, (int)(pxy & 0xffffu), (int)(pxy >> 16), si, (uint64_t)cold[C_PASS * kBlock], rng);
+				} else sample_stream(fr, px, py, si, (uint64_t)pass, rng);
+			}
 #endif
 			bool alive = shade<FEAT>(sc, fr, id, surf, hp, hn, bounce, rp, rd, att, col, rng);
 			bounce++;
 			if(!alive || bounce >= max_bounces) {
-				sum = sum + clamp_hi(col, 1.0f);            // per-sample clamp before averaging (code/raycast.cpp:1263)
 				si++;
 				state = NEED_PATH;
-				if(si == si_end) {
-					store_sum<THROUGH>(job, job.partial + item, sum.x, sum.y, sum.z);
-					state = NEED_PIXEL;
+				if(kCold) {
+					const V3 so_far = v3(__uint_as_float(cold[C_SX * kBlock]), __uint_as_float(cold[C_SY * kBlock]), __uint_as_float(cold[C_SZ * kBlock]));
+					const V3 now = so_far + clamp_hi(col, 1.0f);
+					if(si == (int)cold[C_END * kBlock]) {
+						const size_t it = (size_t)cold[C_ITEM_LO * kBlock] | ((size_t)cold[C_ITEM_HI * kBlock] << 32);
+						store_sum<THROUGH>(job, job.partial + it, now.x, now.y, now.z);
+						state = NEED_PIXEL;
+					} else {
+						cold[C_SX * kBlock] = __float_as_uint(now.x); cold[C_SY * kBlock] = __float_as_uint(now.y); cold[C_SZ * kBlock] = __float_as_uint(now.z);
+					}
+				} else {
+					sum = sum + clamp_hi(col, 1.0f);            // per-sample clamp before averaging (code/raycast.cpp:1263)
+					if(si == si_end) {
+						store_sum<THROUGH>(job, job.partial + item, sum.x, sum.y, sum.z);
+						state = NEED_PIXEL;
+					}
 				}
 			}
 		}
@@ -369,7 +415,11 @@ PT_MARK("shade_end");
 	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, FEAT_ALL, false>(ptl::TraceJob); \
 	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, FEAT_ALL, true>(ptl::TraceJob); \
 	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, FEAT_EVERY, false>(ptl::TraceJob); \
-	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, FEAT_EVERY, true>(ptl::TraceJob);
+	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, FEAT_EVERY, true>(ptl::TraceJob); \
+	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, WAVES_SIX, false>(ptl::TraceJob); \
+	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, WAVES_SIX, true>(ptl::TraceJob); \
+	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, FEAT_ALL | WAVES_SIX, false>(ptl::TraceJob); \
+	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, FEAT_ALL | WAVES_SIX, true>(ptl::TraceJob);
 #if defined(PT_UNIT_BRUTE)
 PT_BRUTE_VARIANTS()
 #elif defined(PT_SPLIT_BRUTE)
@@ -721,14 +771,14 @@ int coop_stats(unsigned long long* out16) {
 }
 
 namespace {
-enum { V_BRUTE_PLAIN = 0, V_BRUTE = 1, V_GRID_LANE = 2, V_GRID_COOP = 3, V_BRUTE_PLANES = 4, V_GRID_COOP_PLANES = 5, V_COUNT = 6 };
+enum { V_BRUTE_PLAIN = 0, V_BRUTE = 1, V_GRID_LANE = 2, V_GRID_COOP = 3, V_BRUTE_PLANES = 4, V_GRID_COOP_PLANES = 5, V_BRUTE_PLAIN_SIX = 6, V_BRUTE_SIX = 7, V_COUNT = 8 };
 static_assert(V_COUNT == ptl::kTraceVariants, "TraceCaps holds one entry per variant");
 // (the per-lane grid walk is the fallback and the A/B partner of the cooperative cast: one variant with everything in it)
 void (*const kTraceKernels[2][V_COUNT])(TraceJob) = {
 	{ pt_k_trace<CAST_BRUTE, 0, false>, pt_k_trace<CAST_BRUTE, FEAT_ALL, false>, pt_k_trace<CAST_GRID_LANE, FEAT_EVERY, false>, pt_k_trace<CAST_GRID_COOP, FEAT_ALL, false>,
-	  pt_k_trace<CAST_BRUTE, FEAT_EVERY, false>, pt_k_trace<CAST_GRID_COOP, FEAT_EVERY, false> },
+	  pt_k_trace<CAST_BRUTE, FEAT_EVERY, false>, pt_k_trace<CAST_GRID_COOP, FEAT_EVERY, false>, pt_k_trace<CAST_BRUTE, WAVES_SIX, false>, pt_k_trace<CAST_BRUTE, FEAT_ALL | WAVES_SIX, false> },
 	{ pt_k_trace<CAST_BRUTE, 0, true>, pt_k_trace<CAST_BRUTE, FEAT_ALL, true>, pt_k_trace<CAST_GRID_LANE, FEAT_EVERY, true>, pt_k_trace<CAST_GRID_COOP, FEAT_ALL, true>,
-	  pt_k_trace<CAST_BRUTE, FEAT_EVERY, true>, pt_k_trace<CAST_GRID_COOP, FEAT_EVERY, true> } };
+	  pt_k_trace<CAST_BRUTE, FEAT_EVERY, true>, pt_k_trace<CAST_GRID_COOP, FEAT_EVERY, true>, pt_k_trace<CAST_BRUTE, WAVES_SIX, true>, pt_k_trace<CAST_BRUTE, FEAT_ALL | WAVES_SIX, true> } };
 }
 
 hipError_t query_trace_caps(TraceCaps* caps) {
@@ -752,8 +802,17 @@ hipError_t launch_trace(const TraceJob& job, const TraceCaps& caps, hipStream_t 
 	static const bool lane_walk = getenv("PT_GRID_PER_LANE") != nullptr;     // A/B switches: per-lane grid walk,
 	static const bool full_brute = getenv("PT_BRUTE_FULL") != nullptr;       // the all-features brute-force variant for every scene
 	const bool planes = (job.scene.features & FEAT_PLANE) != 0;       // a scene with planes runs the variants that know them
-	const int variant = job.scene.brute ? (planes ? V_BRUTE_PLANES : job.scene.features == 0 && !full_brute ? V_BRUTE_PLAIN : V_BRUTE)
-	                                    : (job.scene.coop && !lane_walk ? (planes ? V_GRID_COOP_PLANES : V_GRID_COOP) : V_GRID_LANE);
+	int variant = job.scene.brute ? (planes ? V_BRUTE_PLANES : job.scene.features == 0 && !full_brute ? V_BRUTE_PLAIN : V_BRUTE)
+	                              : (job.scene.coop && !lane_walk ? (planes ? V_GRID_COOP_PLANES : V_GRID_COOP) : V_GRID_LANE);
+	// Six wavefronts per SIMD for the brute-force variants when the launch is long enough to gain by them: a frame of every sample
+	// with at least eight work groups for every wavefront the chip then holds (PT_BRUTE_WAVES=5|6 forces one or the other, for A/B).
+	if(variant == V_BRUTE_PLAIN || variant == V_BRUTE) {
+		static const char* const forced = getenv("PT_BRUTE_WAVES");
+		const int six = variant == V_BRUTE_PLAIN ? V_BRUTE_PLAIN_SIX : V_BRUTE_SIX;
+		const long held = (long)caps.cus * caps.blocks_per_cu[six] * (kBlock / 64);
+		const bool long_launch = job.frame_index < 0 && (long)job.n_groups >= 8 * held;
+		if(forced ? forced[0] == '6' : long_launch) variant = six;
+	}
 	// persistent launch: every resident wave pulls groups of 64 work items until the partition is drained
 	long blocks = ((long)job.n_groups + 3) / 4;
 	long resident = (long)caps.cus * caps.blocks_per_cu[variant];

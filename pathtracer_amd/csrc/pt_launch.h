@@ -144,7 +144,7 @@ struct TraceJob {
 
 // What a launch of the persistent trace kernel needs to know of the device: filled once per context, under that
 // context's device (compute units, resident workgroups per unit of each kernel variant).
-constexpr int kTraceVariants = 6;
+constexpr int kTraceVariants = 8;
 struct TraceCaps { int cus; int blocks_per_cu[kTraceVariants]; };
 hipError_t query_trace_caps(TraceCaps* caps);
 hipError_t launch_trace(const TraceJob& job, const TraceCaps& caps, hipStream_t stream, int* grid_blocks_out);

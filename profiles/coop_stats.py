@@ -35,6 +35,10 @@ if buf[0] == 0:
     for i in range(1, 10):
         print(f"{labels[i]:46s} {buf[i]:14d} {buf[i] / calls:10.2f} {buf[i] / max(1, casts):9.3f}")
     print(f"lanes with a new ray per call: {casts / calls:.1f} of 64; candidates per chunk: {buf[3] / max(1, buf[2]):.1f} of 64")
+    ls = max(1, buf[10])
+    print(f"walking lanes per segment: {buf[10] / max(1, buf[1]):.1f} of 64; of these lane-segments: {100 * buf[11] / ls:.1f} % find no list and go on, "
+          f"{100 * buf[12] / ls:.1f} % find none and leave the grid, {100 * buf[13] / ls:.1f} % find one list")
+    print(f"drains whose last chunk holds at most 16 candidates: {100 * buf[14] / max(1, buf[1]):.1f} % of segments; drains of at most 32 candidates: {100 * buf[15] / max(1, buf[1]):.1f} %")
 else:
     total = buf[0]
     print(f"wave cycles, all wavefronts: {total}; segments {buf[1]}")

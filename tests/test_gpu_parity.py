@@ -594,10 +594,12 @@ def _crops_by_cost(cost, width, height, cw=32, ch=8):
     return crops, cw, ch
 
 
-@pytest.mark.parametrize("name", ["glass-1080p-128spp-d32", "dense100k-4k-256spp-d8"])
+@pytest.mark.parametrize("name", ["glass-1080p-128spp-d32", "dense100k-4k-256spp-d8", "mixed9-1080p-64spp-d16", "demo-1080p-64spp-d8"])
 def test_grid_scenes_at_full_size(gpu, name):
     """The two grid-path configurations at their full sizes (49 refractive entities with depth of field at
-    1080p / 128 spp / depth 32; 100 000 entities on a 64^3-hint grid at 3840x2160 / 256 spp): two runs
+    1080p / 128 spp / depth 32; 100 000 entities on a 64^3-hint grid at 3840x2160 / 256 spp), and the two brute-force
+    frames long enough to run the trace kernel's six-wavefront variants (nine entities of every kind and material; the
+    demo scene; a launch of an eighth of either, as the group at the end renders, runs the five-wavefront ones): two runs
     are bitwise equal, the image is finite and in [0,1], the path count is the oracle's, and crops of the
     full-size image placed by the device's own cost estimate - the dearest tiles, the cheapest busy one, the
     corners, a row through the dearest tile - match the oracle's pixels (same sample ranges, same streams):
@@ -614,6 +616,14 @@ def test_grid_scenes_at_full_size(gpu, name):
     gpu.trace()
     b = gpu.download()
     assert (bits(a) == bits(b)).all()
+    if len(objs) < st.brute_force_below:
+        # the long launch runs six workgroups per compute unit, a one-sample frame of the same scene five
+        blocks_long = gpu.stats().grid_blocks
+        one = default_settings(st.width, st.height, st.spp_wanted, st.max_bounces, seed=st.seed, frame_index=0)
+        gpu.prepare(world, objs, one)
+        gpu.trace()
+        assert blocks_long * 5 == gpu.stats().grid_blocks * 6, (blocks_long, gpu.stats().grid_blocks)
+        gpu.prepare(world, objs, st)
     sc = OracleScene(world, objs, st)
     # A degenerate path (the reference normalises a zero vector on some refraction chains) makes its pixel
     # NaN in the reference's arithmetic too: such pixels must be rare and NaN in the oracle as well.
