@@ -67,11 +67,13 @@ enum { CAST_BRUTE = 0, CAST_GRID_LANE = 1, CAST_GRID_COOP = 2 };
 // unrotated boxes with opaque, smooth materials - the reference's demo scene is one - runs a variant without the
 // unit-space intersectors, Fresnel and Oren-Nayar code, which fits five wavefronts per SIMD instead of four; the
 // frame is bound by each wavefront's own instruction latencies, so the fifth wavefront is worth 13 %.
-// WAVES_SIX (brute-force variants, beside the FEAT bits): the same code compiled for six wavefronts per SIMD (80 registers).
-// On a long frame the sixth wavefront is worth 3 % although twenty cold values of the lean variant then live in scratch
-// memory; the all-features variant, which would spill 36, parks its cold lane state in LDS instead (kCold in the kernel) and
-// gains as much.  A short launch - a progressive frame, an eighth of a frame - loses with it (more wavefronts to start and to
-// feed from the same counters: +14 % on a one-sample frame), so the launch picks by the work there is (launch_trace).
+// WAVES_SIX (brute-force variants, beside the FEAT bits): the same code compiled for six wavefronts per SIMD (80 registers),
+// with the lane state that is only needed once per sample or per item parked in LDS (kCold in the kernel).  On a long frame the
+// sixth wavefront is worth 3 %.  (Left to the compiler, twenty values of the lean variant and 36 of the all-features one go
+// to scratch memory instead: the lean variant is as fast that way, but writes 1.1 GB of spills per 1080p frame; the
+// all-features one is slower than with five wavefronts.)  A short launch - a progressive frame, an eighth of a frame -
+// loses with six (more wavefronts to start and to feed from the same counters: +14 % on a one-sample frame), so the launch
+// picks by the work there is (launch_trace).
 enum { WAVES_SIX = 16 };
 #ifndef PT_PLAIN_WAVES_PER_SIMD
 #define PT_PLAIN_WAVES_PER_SIMD 5
@@ -121,11 +123,11 @@ __global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIM
 	uint4* const stage_a = staged + (kStaged ? (threadIdx.x / 64) * 128 : 0);
 	uint4* const stage_b = stage_a + (kStaged ? 64 : 0);
 	size_t tile_item0 = 0;                     // first range sum of the staged group's range
-	// Cold lane state in LDS (the all-features variant at six wavefronts): what a lane needs once per sample or once per
-	// item - table indices, pixel centre, pixel, the running range sum, where it goes - waits in LDS, a word of all 256
-	// lanes side by side, instead of in fifteen registers that are live across the cast.  (For the lean variant the same
-	// parking measured no better than the compiler's own spills, and worse at five wavefronts: +4 %.)
-	constexpr bool kCold = MODE == CAST_BRUTE && (VARIANT & WAVES_SIX) != 0 && FEAT != 0;
+	// Cold lane state in LDS (the six-wavefront variants): what a lane needs once per sample or once per item - table
+	// indices, pixel centre, pixel, the running range sum, where it goes - waits in LDS, a word of all 256 lanes side by
+	// side, instead of in fifteen registers that are live across the cast.  (At five wavefronts, where the registers are
+	// there, the same parking costs 4 %.)
+	constexpr bool kCold = MODE == CAST_BRUTE && (VARIANT & WAVES_SIX) != 0;
 	enum { C_BASE = 0, C_END, C_LENS, C_PASS, C_OX, C_OY, C_OZ, C_ITEM_LO, C_ITEM_HI, C_PXY, C_SX, C_SY, C_SZ, C_WORDS };
 	__shared__ uint32_t cold_raw[kCold ? C_WORDS * kBlock : 1];
 	uint32_t* const cold = cold_raw + (kCold ? threadIdx.x : 0);
