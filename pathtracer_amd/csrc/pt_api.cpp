@@ -527,6 +527,17 @@ int prepare(pt_ctx* c) {
 		if((rc = upload(c, c->tile_order, order.data(), order.size() * 4))) return rc;
 		j.tile_order = c->tile_order.as<int32_t>();
 	}
+	{
+		// what a group of this launch costs next to one of the demo scene with one sample per item (ptl::TraceJob::group_work)
+		double casts_per_path = 0.5 * s.max_bounces;
+		if(!c->tile_cost_host.empty()) {
+			double sum = 0;
+			for(uint16_t v : c->tile_cost_host) sum += v;
+			casts_per_path = sum / (16.0 * (double)c->tile_cost_host.size());
+		}
+		const double samples_per_item = s.frame_index >= 0 ? 1.0 : std::max(1.0, (double)s.spp_wanted / (double)sum_ranges);
+		j.group_work = (float)(samples_per_item * std::max(1.0, casts_per_path / 1.4) * std::max(1.0, 0.5 * n));
+	}
 
 	// exact path count of this partition (code/raycast.cpp:1045-1048 summed over its pixels)
 	pt_stats& st = c->stats;

@@ -12,6 +12,7 @@
 // the sum; pt_k_resolve then folds a pixel's range sums in range order.  The order of every addition
 // is fixed by the inputs, so the image is a pure function of them (independent of wave scheduling,
 // grid size and GPU count), while the work units are short enough for the frame to end evenly.
+#include <cmath>
 #include <cstdlib>
 
 #include "pt_device.h"
@@ -819,6 +820,21 @@ hipError_t launch_trace(const TraceJob& job, const TraceCaps& caps, hipStream_t 
 	long blocks = ((long)job.n_groups + 3) / 4;
 	long resident = (long)caps.cus * caps.blocks_per_cu[variant];
 	if(blocks > resident) blocks = resident;
+	// A short brute-force launch is faster with fewer workgroups than fit: every workgroup costs its start and its first
+	// fetches, one after the other through the same dispatcher and counters, while the work a group brings is small - a
+	// one-sample frame of the demo scene at 1080p takes 0.186 ms with all 1280, 0.133 ms with 512.  With a cost per workgroup
+	// and a cost per group the best number grows with the root of the launch's work; three times the root of (groups x
+	// group_work) fits the measured optima of one-sample frames of 4 050 ... 57 600 groups (192 ... 720 workgroups) and
+	// leaves every launch of sixteen-sample items at what fits.  Beyond three workgroups per compute unit the rule is not
+	// applied: a one-sample 4K frame (129 600 groups) measures 0.39 - 0.50 ms for 512 ... 1280 workgroups in no order, and
+	// the full grid is as good as any (profiles/r03_ab/grid_size.txt).  PT_GRID_BLOCKS=n forces a size.
+	if(job.scene.brute && job.group_work > 0.0f) {
+		long best = (long)(3.0 * sqrt((double)job.n_groups * (double)job.group_work)) / 8 * 8;
+		if(best < 8) best = 8;
+		if(best < blocks && best <= 3L * caps.cus) blocks = best;
+	}
+	static const char* const grid_env = getenv("PT_GRID_BLOCKS");
+	if(grid_env && atol(grid_env) > 0 && atol(grid_env) <= resident && atol(grid_env) <= ((long)job.n_groups + 3) / 4) blocks = atol(grid_env);
 	if(blocks < 1) blocks = 1;
 	if(grid_blocks_out) *grid_blocks_out = (int)blocks;
 	hipLaunchKernelGGL(kTraceKernels[(job.serial >> 31) & 1u][variant], dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);

@@ -137,6 +137,8 @@ struct TraceJob {
 	uint64_t* stats;            // device: [0] ray casts
 	int tiles_x, tiles_y;
 	int n_groups;               // tiles owned by this partition x ranges
+	float group_work;           // what a group costs, in samples per item of the demo scene's kind (a path of 1.4 casts against two entities):
+	                            // samples per item x casts per path / 1.4 x entities / 2, from the tile-cost probe; sizes short brute-force launches
 	int part_index, part_count;
 	int frame_index;            // -1: every sample; >= 0: one sample, progressive
 	int compact;
