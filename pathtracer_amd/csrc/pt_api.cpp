@@ -435,7 +435,7 @@ int prepare(pt_ctx* c) {
 	PT_HIP(c, c->counter.reserve(8192));      // two sets of group counters, one cache line each; launches alternate between them
 	PT_HIP(c, hipMemsetAsync(c->counter.p, 0, 8192, c->stream));
 	c->counter_set = 0;
-	PT_HIP(c, c->stats_dev.reserve(256));
+	PT_HIP(c, c->stats_dev.reserve(ptl::kStatBytes));
 	// range sums of every pixel slot, and the quotients x/width, y/height (the divisions of code/raycast.cpp:1050)
 	const int sum_ranges = pt_sample_ranges(&s);
 	int ranges_log2 = 0;
@@ -447,7 +447,7 @@ int prepare(pt_ctx* c) {
 		for(int y = 0; y < s.height; y++) fracs[(size_t)s.width + (size_t)y] = (float)y / (float)s.height;
 		if((rc = upload(c, c->fracs, fracs.data(), fracs.size() * 4))) return rc;
 	}
-	PT_HIP(c, hipMemsetAsync(c->stats_dev.p, 0, 256, c->stream));
+	PT_HIP(c, hipMemsetAsync(c->stats_dev.p, 0, ptl::kStatBytes, c->stream));
 
 	ptl::TraceJob& j = c->job;
 	j = ptl::TraceJob{};
@@ -641,10 +641,12 @@ int collect(pt_ctx* c) {
 	}
 	if(!pend.empty()) {
 		// on the library's stream: the caller has waited for every stream the launches went to
-		uint64_t rays = 0;
-		PT_HIP(c, hipMemcpyAsync(&rays, c->stats_dev.p, sizeof rays, hipMemcpyDeviceToHost, c->stream));
-		PT_HIP(c, hipMemsetAsync(c->stats_dev.p, 0, 256, c->stream));
+		uint64_t shards[ptl::kStatBytes / 8];
+		PT_HIP(c, hipMemcpyAsync(shards, c->stats_dev.p, sizeof shards, hipMemcpyDeviceToHost, c->stream));
+		PT_HIP(c, hipMemsetAsync(c->stats_dev.p, 0, ptl::kStatBytes, c->stream));
 		PT_HIP(c, hipStreamSynchronize(c->stream));
+		uint64_t rays = 0;
+		for(int k = 0; k < ptl::kStatShards; k++) rays += shards[k * ptl::kStatStride];
 		std::lock_guard<std::mutex> l(c->mu);             // pt_get_stats may be reading from another thread
 		c->kernel_ms_sum = sum;
 		c->kernel_launches = (int)pend.size();

@@ -404,7 +404,7 @@ PT_MARK("shade_end");
 #endif
 	// ray-cast count: one atomic per wave
 	if(job.stats) {
-		if(lane == 0) atomicAdd((unsigned long long*)job.stats, (unsigned long long)casts);
+		if(lane == 0) atomicAdd((unsigned long long*)job.stats + (blockIdx.x % ptl::kStatShards) * ptl::kStatStride, (unsigned long long)casts);
 	}
 }
 
