@@ -110,6 +110,10 @@ __global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIM
 	// the blue-noise bucket offsets (at most 17 words) are read at every hand-out: keep them in LDS
 	__shared__ int bucket[20];
 	if((int)threadIdx.x <= tile_w * tile_w) bucket[threadIdx.x] = sc.offsets[threadIdx.x];
+	// which group counters a wavefront of this workgroup has found dry (they only grow): the others need not ask again.  Every
+	// wavefront ends by finding all eight dry, each question an atomic operation that queues at its counter with everybody else's
+	__shared__ uint32_t dry_shards;
+	if(MODE != CAST_GRID_COOP && threadIdx.x == 0) dry_shards = 0u;
 	// the counters of the launch after this one (nobody reads them before this kernel has ended)
 	if(blockIdx.x == 0 && threadIdx.x < kShards) job.group_counter_next[threadIdx.x * kShardStride] = 0u;
 	__syncthreads();
@@ -177,9 +181,12 @@ PT_MARK("loop_begin");
 				uint32_t g = 0x80000000u;
 				if(lane == 0) {
 					for(uint32_t tried = 0; tried < kShards; tried++) {
-						const uint32_t count = atomicAdd(job.group_counter + shard * kShardStride, 1u);
-						const uint32_t cand = count < 0x04000000u ? count * kShards + shard : 0x80000000u;
-						if(cand < (uint32_t)job.n_groups) { g = cand; break; }
+						if(!kStaged || ((*(volatile uint32_t*)&dry_shards >> shard) & 1u) == 0u) {      // (the cooperative cast does without: no register to spare, and long launches)
+							const uint32_t count = atomicAdd(job.group_counter + shard * kShardStride, 1u);
+							const uint32_t cand = count < 0x04000000u ? count * kShards + shard : 0x80000000u;
+							if(cand < (uint32_t)job.n_groups) { g = cand; break; }
+							if(kStaged) atomicOr(&dry_shards, 1u << shard);
+						}
 						shard = (shard + 1u) % kShards;
 					}
 					if(g != 0x80000000u && (g & (kAbortPoll - 1u)) == 0u) {
