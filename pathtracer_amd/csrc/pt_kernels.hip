@@ -815,12 +815,12 @@ hipError_t launch_trace(const TraceJob& job, const TraceCaps& caps, hipStream_t 
 	int variant = job.scene.brute ? (planes ? V_BRUTE_PLANES : job.scene.features == 0 && !full_brute ? V_BRUTE_PLAIN : V_BRUTE)
 	                              : (job.scene.coop && !lane_walk ? (planes ? V_GRID_COOP_PLANES : V_GRID_COOP) : V_GRID_LANE);
 	// Six wavefronts per SIMD for the brute-force variants when the launch is long enough to gain by them: a frame of every sample
-	// with at least eight work groups for every wavefront the chip then holds (PT_BRUTE_WAVES=5|6 forces one or the other, for A/B).
+	// with at least four work groups for every wavefront the chip then holds (PT_BRUTE_WAVES=5|6 forces one or the other, for A/B).
 	if(variant == V_BRUTE_PLAIN || variant == V_BRUTE) {
 		static const char* const forced = getenv("PT_BRUTE_WAVES");
 		const int six = variant == V_BRUTE_PLAIN ? V_BRUTE_PLAIN_SIX : V_BRUTE_SIX;
 		const long held = (long)caps.cus * caps.blocks_per_cu[six] * (kBlock / 64);
-		const bool long_launch = job.frame_index < 0 && (long)job.n_groups >= 8 * held;
+		const bool long_launch = job.frame_index < 0 && (long)job.n_groups >= 4 * held;
 		if(forced ? forced[0] == '6' : long_launch) variant = six;
 	}
 	// persistent launch: every resident wave pulls groups of 64 work items until the partition is drained
@@ -830,15 +830,15 @@ hipError_t launch_trace(const TraceJob& job, const TraceCaps& caps, hipStream_t 
 	// A short brute-force launch is faster with fewer workgroups than fit: every workgroup costs its start and its first
 	// fetches, one after the other through the same dispatcher and counters, while the work a group brings is small - a
 	// one-sample frame of the demo scene at 1080p takes 0.186 ms with all 1280, 0.133 ms with 512.  With a cost per workgroup
-	// and a cost per group the best number grows with the root of the launch's work; three times the root of (groups x
-	// group_work) fits the measured optima of one-sample frames of 4 050 ... 57 600 groups (192 ... 720 workgroups) and
-	// leaves every launch of sixteen-sample items at what fits.  Beyond three workgroups per compute unit the rule is not
+	// and a cost per group the best number grows with the root of the launch's work; four times the root of (groups x
+	// group_work) fits the measured optima of one-sample frames of 4 050 ... 32 400 groups (256 ... 768 workgroups) and
+	// leaves every launch of sixteen-sample items at what fits.  Beyond four workgroups per compute unit the rule is not
 	// applied: a one-sample 4K frame (129 600 groups) measures 0.39 - 0.50 ms for 512 ... 1280 workgroups in no order, and
 	// the full grid is as good as any (profiles/r03_ab/grid_size.txt).  PT_GRID_BLOCKS=n forces a size.
 	if(job.scene.brute && job.group_work > 0.0f) {
-		long best = (long)(3.0 * sqrt((double)job.n_groups * (double)job.group_work)) / 8 * 8;
+		long best = (long)(4.0 * sqrt((double)job.n_groups * (double)job.group_work)) / 8 * 8;
 		if(best < 8) best = 8;
-		if(best < blocks && best <= 3L * caps.cus) blocks = best;
+		if(best < blocks && best <= 4L * caps.cus) blocks = best;
 	}
 	static const char* const grid_env = getenv("PT_GRID_BLOCKS");
 	if(grid_env && atol(grid_env) > 0 && atol(grid_env) <= resident && atol(grid_env) <= ((long)job.n_groups + 3) / 4) blocks = atol(grid_env);

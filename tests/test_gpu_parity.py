@@ -617,10 +617,10 @@ def test_grid_scenes_at_full_size(gpu, name):
     b = gpu.download()
     assert (bits(a) == bits(b)).all()
     if len(objs) < st.brute_force_below:
-        # the long launch runs six workgroups per compute unit, a quarter of the same frame five
+        # the long launch runs six workgroups per compute unit, an eighth of the same frame five
         blocks_long = gpu.stats().grid_blocks
-        quarter = default_settings(st.width, st.height, st.spp_wanted, st.max_bounces, seed=st.seed, part_index=0, part_count=4)
-        gpu.prepare(world, objs, quarter)
+        eighth = default_settings(st.width, st.height, st.spp_wanted, st.max_bounces, seed=st.seed, part_index=0, part_count=8)
+        gpu.prepare(world, objs, eighth)
         gpu.trace()
         assert blocks_long * 5 == gpu.stats().grid_blocks * 6, (blocks_long, gpu.stats().grid_blocks)
         gpu.prepare(world, objs, st)
