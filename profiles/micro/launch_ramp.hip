@@ -16,28 +16,41 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void touch(unsigned* out, int 
 	if(v == 0xdeadbeefu) out[0] = v;
 }
 
-template <int W, int L>
+// the same with 96 vector registers allocated, as the trace kernel has
+template <int WAVES_PER_SIMD, int LDS_BYTES>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void touch96(unsigned* out, int spin) {
+	__shared__ unsigned lds[LDS_BYTES / 4];
+	lds[threadIdx.x] = threadIdx.x;
+	__syncthreads();
+	unsigned v = lds[(threadIdx.x + 1) & 255];
+	asm volatile("v_mov_b32 v95, 0" ::: "v95");
+	for(int i = 0; i < spin; i++) v = v * 1664525u + 1013904223u;
+	if(v == 0xdeadbeefu) out[0] = v;
+}
+
+template <int W, int L, bool FAT = false>
 static void run(const char* name, int spin) {
 	unsigned* out;
-	hipMalloc(&out, 4);
+	(void)hipMalloc(&out, 4);
 	hipEvent_t a, b;
-	hipEventCreate(&a); hipEventCreate(&b);
+	(void)hipEventCreate(&a); (void)hipEventCreate(&b);
 	printf("%-34s", name);
 	for(int blocks : { 256, 512, 1024, 1280, 1536, 2560, 5120, 10240 }) {
 		std::vector<float> ms;
 		for(int rep = 0; rep < 30; rep++) {
-			hipEventRecord(a, 0);
-			hipLaunchKernelGGL((touch<W, L>), dim3(blocks), dim3(256), 0, 0, out, spin);
-			hipEventRecord(b, 0);
-			hipEventSynchronize(b);
-			float t; hipEventElapsedTime(&t, a, b);
+			(void)hipEventRecord(a, 0);
+			if(FAT) hipLaunchKernelGGL((touch96<W, L>), dim3(blocks), dim3(256), 0, 0, out, spin);
+			else hipLaunchKernelGGL((touch<W, L>), dim3(blocks), dim3(256), 0, 0, out, spin);
+			(void)hipEventRecord(b, 0);
+			(void)hipEventSynchronize(b);
+			float t; (void)hipEventElapsedTime(&t, a, b);
 			ms.push_back(t);
 		}
 		std::sort(ms.begin(), ms.end());
 		printf(" %6d: %6.1f us", blocks, ms[ms.size() / 2] * 1e3f);
 	}
 	printf("\n");
-	hipFree(out);
+	(void)hipFree(out);
 }
 
 int main() {
@@ -45,6 +58,8 @@ int main() {
 	run<5, 8192>("5 waves/SIMD, 8 KB LDS, empty", 0);
 	run<6, 21504>("6 waves/SIMD, 21 KB LDS, empty", 0);
 	run<4, 40960>("4 waves/SIMD, 40 KB LDS, empty", 0);
+	run<5, 8192, true>("5 waves/SIMD, 8 KB, 96 VGPRs, empty", 0);
+	run<6, 21504, true>("6 waves/SIMD, 21 KB, 80+ VGPRs", 0);
 	run<5, 8192>("5 waves/SIMD, 8 KB LDS, 2000 steps", 2000);
 	run<5, 8192>("5 waves/SIMD, 8 KB LDS, 20000 steps", 20000);
 	return 0;
