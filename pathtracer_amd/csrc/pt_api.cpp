@@ -583,6 +583,10 @@ int trace(pt_ctx* c, float* d_rgb, hipStream_t stream, bool sync, bool write_thr
 	if(s != c->stream && std::find(c->used_streams.begin(), c->used_streams.end(), s) == c->used_streams.end()) c->used_streams.push_back(s);
 	if(++c->serial >= 0x80000000u) c->serial = 1;
 	job.serial = c->serial | (write_through ? 0x80000000u : 0u);
+	// A progressive frame traced synchronously goes straight into the accumulation buffer and the image; an asynchronous render
+	// keeps the range sums, which its snapshots and its abort read.  (PT_NO_PIXEL_STORE=1: range sums and the resolve pass, for A/B.)
+	static const bool no_pixel_store = getenv("PT_NO_PIXEL_STORE") != nullptr;
+	job.pixel_store = (job.frame_index >= 0 && job.accum != nullptr && !write_through && !no_pixel_store) ? 1 : 0;
 	job.group_counter = c->counter.as<uint32_t>() + (size_t)c->counter_set * 1024;
 	job.group_counter_next = c->counter.as<uint32_t>() + (size_t)(c->counter_set ^ 1) * 1024;
 	*c->progress_word = 0;
@@ -608,7 +612,7 @@ int trace(pt_ctx* c, float* d_rgb, hipStream_t stream, bool sync, bool write_thr
 	int blocks = 0;
 	PT_HIP(c, ptl::launch_trace(job, c->caps, s, &blocks));
 	if(timed) PT_HIP(c, hipEventRecord(e1, s));
-	PT_HIP(c, ptl::launch_resolve(job, c->fb_floats / 3, s));
+	if(!job.pixel_store) PT_HIP(c, ptl::launch_resolve(job, c->fb_floats / 3, s));
 	if(timed) {
 		PT_HIP(c, hipEventRecord(e2, s));
 		std::lock_guard<std::mutex> l(c->mu);

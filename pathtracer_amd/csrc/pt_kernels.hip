@@ -50,6 +50,26 @@ __device__ __forceinline__ void store_sum(const ptl::TraceJob& job, float4* at, 
 	else *at = make_float4(v.x, v.y, v.z, v.w);
 }
 
+// How a finished item leaves the kernel (STORE): 0 as a range sum, 1 as a range sum written through the caches, 2 - the
+// progressive frames of a synchronous trace, one sample per pixel and therefore one range - straight into the
+// accumulation buffer and the image, with the operations of pt_k_resolve's progressive branch in its order (the item's
+// index is the pixel's slot then): no range sum, and no resolve pass after the frame.  `traced` false: a pixel whose bucket
+// holds no sample.
+enum { STORE_SUM = 0, STORE_SUM_THROUGH = 1, STORE_PIXEL = 2 };
+template <int STORE>
+__device__ __forceinline__ void finish_item(const ptl::TraceJob& job, size_t item, V3 sum, bool traced) {
+	if(STORE == STORE_PIXEL) {
+		float* o = job.fb + item * 3;
+		if(!traced) { o[0] = 0; o[1] = 0; o[2] = 0; return; }
+		float* a = job.accum + item * 3;
+		V3 total = sum;
+		if(job.frame_index > 0) total = v3(a[0] + sum.x, a[1] + sum.y, a[2] + sum.z);
+		a[0] = total.x; a[1] = total.y; a[2] = total.z;
+		const V3 c = clamp_hi(total / (float)(job.frame_index + 1), 1.0f);
+		o[0] = c.x; o[1] = c.y; o[2] = c.z;
+	} else store_sum<STORE == STORE_SUM_THROUGH>(job, job.partial + item, sum.x, sum.y, sum.z);
+}
+
 // Pixel centre on the image plane (code/raycast.cpp:1050-1057).  The two quotients x/width and
 // y/height come from tables the host filled with the same divisions.
 __device__ __forceinline__ V3 pixel_origin_tab(const ptl::TraceJob& job, FrameRef fr, int x, int y) {
@@ -88,7 +108,7 @@ enum { WAVES_SIX = 16 };
 
 // The trace kernel has a name other units can see: its brute-force variants are compiled as a unit of their own (below).
 namespace ptk {
-template <int MODE, int VARIANT, bool THROUGH>
+template <int MODE, int VARIANT, int STORE>
 __global__ __launch_bounds__(kBlock, MODE != CAST_BRUTE ? PT_TRACE_WAVES_PER_SIMD : (VARIANT & WAVES_SIX) ? 6 : (VARIANT & FEAT_EVERY) == 0 ? PT_PLAIN_WAVES_PER_SIMD : PT_BRUTE_WAVES_PER_SIMD) void pt_k_trace(ptl::TraceJob job) {
 	constexpr int FEAT = VARIANT & FEAT_EVERY;
 #ifdef PT_COOP_TIMING
@@ -232,7 +252,7 @@ PT_MARK("loop_begin");
 						}
 						if(s0 == s1) {
 							// nothing to trace (a bucket without samples, code/raycast.cpp:1270, or fewer samples than ranges)
-							store_sum<THROUGH>(job, job.partial + tile_item0 + slot, 0.0f, 0.0f, 0.0f);
+							finish_item<STORE>(job, tile_item0 + slot, v3(0, 0, 0), false);
 						} else {
 							const V3 o = pixel_origin_tab(job, fr, x, y);
 							a = make_uint4((uint32_t)first, (uint32_t)s0 | ((uint32_t)s1 << 16), fr->aperture != 0.0f ? (uint32_t)lens_start(fr, x, y) : 0u, round);
@@ -293,7 +313,7 @@ PT_MARK("loop_begin");
 					} else { si = 0; si_end = 0; }
 					if(si == si_end) {
 						// nothing to trace (a bucket without samples, code/raycast.cpp:1270, or fewer samples than ranges)
-						store_sum<THROUGH>(job, job.partial + item, 0.0f, 0.0f, 0.0f);
+						finish_item<STORE>(job, item, v3(0, 0, 0), false);
 					} else {
 						lens = fr->aperture != 0.0f ? lens_start(fr, px, py) : 0;
 						if(MODE != CAST_GRID_COOP) origin = pixel_origin_tab(job, fr, px, py);
@@ -377,7 +397,7 @@ PT_MARK("cast_end");
 					const V3 now = so_far + clamp_hi(col, 1.0f);
 					if(si == (int)cold[C_END * kBlock]) {
 						const size_t it = (size_t)cold[C_ITEM_LO * kBlock] | ((size_t)cold[C_ITEM_HI * kBlock] << 32);
-						store_sum<THROUGH>(job, job.partial + it, now.x, now.y, now.z);
+						finish_item<STORE>(job, it, now, true);
 						state = NEED_PIXEL;
 					} else {
 						cold[C_SX * kBlock] = __float_as_uint(now.x); cold[C_SY * kBlock] = __float_as_uint(now.y); cold[C_SZ * kBlock] = __float_as_uint(now.z);
@@ -385,7 +405,7 @@ PT_MARK("cast_end");
 				} else {
 					sum = sum + clamp_hi(col, 1.0f);            // per-sample clamp before averaging (code/raycast.cpp:1263)
 					if(si == si_end) {
-						store_sum<THROUGH>(job, job.partial + item, sum.x, sum.y, sum.z);
+						finish_item<STORE>(job, item, sum, true);
 						state = NEED_PIXEL;
 					}
 				}
@@ -429,7 +449,10 @@ PT_MARK("shade_end");
 	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, WAVES_SIX, false>(ptl::TraceJob); \
 	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, WAVES_SIX, true>(ptl::TraceJob); \
 	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, FEAT_ALL | WAVES_SIX, false>(ptl::TraceJob); \
-	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, FEAT_ALL | WAVES_SIX, true>(ptl::TraceJob);
+	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, FEAT_ALL | WAVES_SIX, true>(ptl::TraceJob); \
+	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, 0, STORE_PIXEL>(ptl::TraceJob); \
+	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, FEAT_ALL, STORE_PIXEL>(ptl::TraceJob); \
+	PREFIX template __global__ void pt_k_trace<CAST_BRUTE, FEAT_EVERY, STORE_PIXEL>(ptl::TraceJob);
 #if defined(PT_UNIT_BRUTE)
 PT_BRUTE_VARIANTS()
 #elif defined(PT_SPLIT_BRUTE)
@@ -784,11 +807,14 @@ namespace {
 enum { V_BRUTE_PLAIN = 0, V_BRUTE = 1, V_GRID_LANE = 2, V_GRID_COOP = 3, V_BRUTE_PLANES = 4, V_GRID_COOP_PLANES = 5, V_BRUTE_PLAIN_SIX = 6, V_BRUTE_SIX = 7, V_COUNT = 8 };
 static_assert(V_COUNT == ptl::kTraceVariants, "TraceCaps holds one entry per variant");
 // (the per-lane grid walk is the fallback and the A/B partner of the cooperative cast: one variant with everything in it)
-void (*const kTraceKernels[2][V_COUNT])(TraceJob) = {
+void (*const kTraceKernels[3][V_COUNT])(TraceJob) = {
 	{ pt_k_trace<CAST_BRUTE, 0, false>, pt_k_trace<CAST_BRUTE, FEAT_ALL, false>, pt_k_trace<CAST_GRID_LANE, FEAT_EVERY, false>, pt_k_trace<CAST_GRID_COOP, FEAT_ALL, false>,
 	  pt_k_trace<CAST_BRUTE, FEAT_EVERY, false>, pt_k_trace<CAST_GRID_COOP, FEAT_EVERY, false>, pt_k_trace<CAST_BRUTE, WAVES_SIX, false>, pt_k_trace<CAST_BRUTE, FEAT_ALL | WAVES_SIX, false> },
 	{ pt_k_trace<CAST_BRUTE, 0, true>, pt_k_trace<CAST_BRUTE, FEAT_ALL, true>, pt_k_trace<CAST_GRID_LANE, FEAT_EVERY, true>, pt_k_trace<CAST_GRID_COOP, FEAT_ALL, true>,
-	  pt_k_trace<CAST_BRUTE, FEAT_EVERY, true>, pt_k_trace<CAST_GRID_COOP, FEAT_EVERY, true>, pt_k_trace<CAST_BRUTE, WAVES_SIX, true>, pt_k_trace<CAST_BRUTE, FEAT_ALL | WAVES_SIX, true> } };
+	  pt_k_trace<CAST_BRUTE, FEAT_EVERY, true>, pt_k_trace<CAST_GRID_COOP, FEAT_EVERY, true>, pt_k_trace<CAST_BRUTE, WAVES_SIX, true>, pt_k_trace<CAST_BRUTE, FEAT_ALL | WAVES_SIX, true> },
+	// progressive frames written straight to the image (a one-sample frame never runs a six-wavefront variant: their places hold the five-wavefront ones)
+	{ pt_k_trace<CAST_BRUTE, 0, STORE_PIXEL>, pt_k_trace<CAST_BRUTE, FEAT_ALL, STORE_PIXEL>, pt_k_trace<CAST_GRID_LANE, FEAT_EVERY, STORE_PIXEL>, pt_k_trace<CAST_GRID_COOP, FEAT_ALL, STORE_PIXEL>,
+	  pt_k_trace<CAST_BRUTE, FEAT_EVERY, STORE_PIXEL>, pt_k_trace<CAST_GRID_COOP, FEAT_EVERY, STORE_PIXEL>, pt_k_trace<CAST_BRUTE, 0, STORE_PIXEL>, pt_k_trace<CAST_BRUTE, FEAT_ALL, STORE_PIXEL> } };
 }
 
 hipError_t query_trace_caps(TraceCaps* caps) {
@@ -844,7 +870,7 @@ hipError_t launch_trace(const TraceJob& job, const TraceCaps& caps, hipStream_t 
 	if(grid_env && atol(grid_env) > 0 && atol(grid_env) <= resident && atol(grid_env) <= ((long)job.n_groups + 3) / 4) blocks = atol(grid_env);
 	if(blocks < 1) blocks = 1;
 	if(grid_blocks_out) *grid_blocks_out = (int)blocks;
-	hipLaunchKernelGGL(kTraceKernels[(job.serial >> 31) & 1u][variant], dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
+	hipLaunchKernelGGL(kTraceKernels[job.pixel_store ? STORE_PIXEL : (job.serial >> 31) & 1u][variant], dim3((unsigned)blocks), dim3(kBlock), 0, stream, job);
 	return hipGetLastError();
 }
 

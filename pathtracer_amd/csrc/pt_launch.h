@@ -148,6 +148,8 @@ struct TraceJob {
 	int part_index, part_count;
 	int frame_index;            // -1: every sample; >= 0: one sample, progressive
 	int compact;
+	int pixel_store;            // a progressive frame (frame_index >= 0, one range) whose lanes add their sample to `accum` and write the pixel
+	                            // themselves: no range sums are written and launch_resolve is not to follow (the caller of launch_trace sets it)
 };
 
 // What a launch of the persistent trace kernel needs to know of the device: filled once per context, under that
