@@ -284,7 +284,7 @@ int pt_debug_srgb8(pt_ctx* ctx, const float* linear, size_t n, uint8_t* out);
 int pt_debug_srgb8_sweep(pt_ctx* ctx, uint32_t first_bits, uint64_t count, uint64_t* mismatches, uint64_t* histogram256);
 
 /* The range count a render uses: settings->sample_ranges, or for 0 the largest power of two not
- * above spp_wanted / 16, within 1..8.  Progressive frames trace one sample per pixel: always 1.
+ * above spp_wanted / 16, within 1..16.  Progressive frames trace one sample per pixel: always 1.
  * Negative on a bad value.  Pure arithmetic. */
 int pt_sample_ranges(const pt_settings* settings);
 

@@ -1059,13 +1059,13 @@ static inline void sample_stream(const pto_scene* s, int x, int y, int si, uint6
 }
 
 /* Range count of a render under PT_SEED_PER_SAMPLE (include/pt_api.h, pt_settings.sample_ranges):
- * the asked count, or for 0 the largest power of two not above spp_wanted / 16, within 1..8.  The
+ * the asked count, or for 0 the largest power of two not above spp_wanted / 16, within 1..16.  The
  * reference itself adds all samples of a pixel in one sequence (code/raycast.cpp:1263). */
 static int sample_ranges(const pt_settings* st) {
 	if(st->frame_index >= 0) return 1;
 	if(st->sample_ranges > 0) return st->sample_ranges;
 	int ranges = 1;
-	while(ranges < 8 && ranges * 2 * 16 <= st->spp_wanted) ranges *= 2;
+	while(ranges < 16 && ranges * 2 * 16 <= st->spp_wanted) ranges *= 2;
 	return ranges;
 }
 

@@ -1833,7 +1833,7 @@ int pt_sample_ranges(const pt_settings* s) {
 	if(s->frame_index >= 0) return 1;
 	if(asked > 0) return asked;
 	int ranges = 1;
-	while(ranges < 8 && ranges * 2 * 16 <= s->spp_wanted) ranges *= 2;
+	while(ranges < 16 && ranges * 2 * 16 <= s->spp_wanted) ranges *= 2;
 	return ranges;
 }
 

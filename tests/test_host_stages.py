@@ -128,7 +128,7 @@ def test_sample_ranges_rule(core_lib):
     for spp in (1, 16, 31, 32, 64, 127, 128, 256, 4096):
         st = default_settings(64, 36, spp, 8)
         got[spp] = core_lib.pt_sample_ranges(C.byref(st))
-    assert got == {1: 1, 16: 1, 31: 1, 32: 2, 64: 4, 127: 4, 128: 8, 256: 8, 4096: 8}
+    assert got == {1: 1, 16: 1, 31: 1, 32: 2, 64: 4, 127: 4, 128: 8, 256: 16, 4096: 16}
     st = default_settings(64, 36, 64, 8, sample_ranges=16)
     assert core_lib.pt_sample_ranges(C.byref(st)) == 16
     st.frame_index = 3
