@@ -46,8 +46,9 @@ print(open(os.path.join(dst, "pmc_summary.csv")).read())
 if "--latest" in sys.argv:
     workload = sys.argv[sys.argv.index("--latest") + 1]
     def mean(counter, frag):
-        # the trace kernel has a write-through twin (asynchronous renders: bench.py's end_to_end leg); the timed steps run the plain one
-        v = [x for (k, c), xs in acc.items() if c == counter and frag in k and "true>" not in k for x in xs]
+        # the trace kernel has a write-through twin (asynchronous renders: bench.py's end_to_end leg; last template argument 1, "true" in
+        # older builds); the timed steps run the plain one
+        v = [x for (k, c), xs in acc.items() if c == counter and frag in k and "true>" not in k and ", 1>(" not in k for x in xs]
         return sum(v) / len(v) if v else 0.0
     # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so reads are doubled
     trace = 2 * 1024 * mean("FETCH_SIZE", "pt_k_trace") + 1024 * mean("WRITE_SIZE", "pt_k_trace")
