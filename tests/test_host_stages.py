@@ -60,6 +60,8 @@ CASES = {
     "glass": lambda: scenes.glass_scene(seed=3, per_type=16),
     "crowded": lambda: scenes.mixed_scene(seed=9, n=300, spread=12.0),
     "dense2k": lambda: scenes.dense_scene(n=2000, seed=4, half_extent=40.0, height=20.0),
+    "planes_small": lambda: scenes.planes_small_scene(),
+    "planes_grid": lambda: scenes.planes_grid_scene(),
 }
 
 
