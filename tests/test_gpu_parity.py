@@ -616,7 +616,7 @@ def test_grid_scenes_at_full_size(gpu, name):
     gpu.trace()
     b = gpu.download()
     assert (bits(a) == bits(b)).all()
-    if len(objs) < st.brute_force_below:
+    if len(objs) < st.brute_force_below and "PT_BRUTE_WAVES" not in os.environ and "PT_GRID_BLOCKS" not in os.environ:
         # the long launch runs six workgroups per compute unit, an eighth of the same frame five
         blocks_long = gpu.stats().grid_blocks
         eighth = default_settings(st.width, st.height, st.spp_wanted, st.max_bounces, seed=st.seed, part_index=0, part_count=8)
