@@ -222,6 +222,13 @@ void reorder_lists(const ptl::GridDev& g, bool to_device, std::vector<uint32_t>*
 // kLongestDeviceList entities: the ordering pass sorts a list with one thread, so the host builds then.
 constexpr uint32_t kLongestDeviceList = 4096;
 constexpr size_t kSnapHalfBytes = 8u << 20;      // one half of the pinned landing area of pt_render_snapshot
+// Entities are left out of the cells their own bounding sphere does not reach (ptl::reaches_cell); PT_NO_CELL_CULL=1 keeps the
+// reference's lists on the device, for A/B (pt_host_grid always reports the reference's).
+bool cell_cull() {
+	static const bool off = getenv("PT_NO_CELL_CULL") != nullptr;
+	return !off;
+}
+
 int grid_build_device(pt_ctx* c, const std::vector<float>& rec, int n, const pt::GridDesc& gd, size_t* item_total, bool* done) {
 	*done = false;
 	const size_t cells = (size_t)gd.cells();
@@ -246,6 +253,7 @@ int grid_build_device(pt_ctx* c, const std::vector<float>& rec, int n, const pt:
 	job.cursor = c->grid_cursor.as<uint32_t>();
 	job.block_sums = c->grid_sums.as<uint32_t>();
 	job.longest = c->grid_sums.as<uint32_t>() + ptl::grid_scan_blocks(cells);
+	job.cull = cell_cull() ? 1 : 0;
 	PT_HIP(c, ptl::launch_grid_count_scan(job, cells, c->stream));
 	uint32_t total = 0, longest = 0;
 	PT_HIP(c, hipMemcpyAsync(&total, job.cell_start + cells, 4, hipMemcpyDeviceToHost, c->stream));
@@ -373,6 +381,23 @@ int prepare(pt_ctx* c) {
 		if(have_grid) pt::build_grid(rec.data(), n, s.grid_hint, &gd, &cell_start, &cell_items);
 		const ptl::GridDev layout = grid_dev(gd);
 		reorder_lists(layout, true, &cell_start, &cell_items);
+		if(cell_cull() && have_grid) {
+			// the lists without the entities that stay clear of the cell (in place: the write position never passes the read position)
+			const int64_t all = gd.cells();
+			size_t out = 0;
+			for(int64_t cell = 0; cell < all; cell++) {
+				uint32_t at[3];
+				ptl::grid_cell_coords(layout, (size_t)cell, at);
+				const uint32_t k0 = cell_start[(size_t)cell], k1 = cell_start[(size_t)cell + 1];
+				cell_start[(size_t)cell] = (uint32_t)out;
+				for(uint32_t k = k0; k < k1; k++) {
+					const float* r = rec.data() + (size_t)cell_items[k] * PT_F_STRIDE;
+					if(ptl::reaches_cell(layout, r[PT_F_POS], r[PT_F_POS + 1], r[PT_F_POS + 2], pt::filter_radius(r), (int)at[0], (int)at[1], (int)at[2])) cell_items[out++] = cell_items[k];
+				}
+			}
+			cell_start[(size_t)all] = (uint32_t)out;
+			cell_items.resize(out);
+		}
 		item_total = cell_items.size();
 		if(item_total > ptl::CELL_START_MASK) return fail(c, PT_ERR_LIMIT, "the grid's cell lists hold %zu entries, more than the %u an index into them may address", item_total, ptl::CELL_START_MASK);
 		if((rc = upload(c, c->cell_items, cell_items.data(), cell_items.size() * 4))) return rc;
@@ -392,12 +417,17 @@ int prepare(pt_ctx* c) {
 				const float* r = rec.data() + (size_t)id * PT_F_STRIDE;
 				const uint32_t lo = ranges[(size_t)id * 2], hi = ranges[(size_t)id * 2 + 1];
 				uint32_t tag = (lo >> 30) | ((hi >> 30) << 2);
+				const float radius = pt::filter_radius(r);
 				for(int a = 0; a < 3; a++) {
-					if(at[a] > ((lo >> (10 * a)) & 1023u)) tag |= 1u << (3 + 2 * a);
-					if(at[a] < ((hi >> (10 * a)) & 1023u)) tag |= 1u << (4 + 2 * a);
+					// listed in the neighbour across this face: inside the entity's cell range, and not left out of that cell's list
+					int nb[3] = { (int)at[0], (int)at[1], (int)at[2] };
+					nb[a] = (int)at[a] - 1;
+					if(at[a] > ((lo >> (10 * a)) & 1023u) && (!cell_cull() || ptl::reaches_cell(layout, r[PT_F_POS], r[PT_F_POS + 1], r[PT_F_POS + 2], radius, nb[0], nb[1], nb[2]))) tag |= 1u << (3 + 2 * a);
+					nb[a] = (int)at[a] + 1;
+					if(at[a] < ((hi >> (10 * a)) & 1023u) && (!cell_cull() || ptl::reaches_cell(layout, r[PT_F_POS], r[PT_F_POS + 1], r[PT_F_POS + 2], radius, nb[0], nb[1], nb[2]))) tag |= 1u << (4 + 2 * a);
 				}
 				uint32_t w[4];
-				ptl::pack_entry(r[PT_F_POS], r[PT_F_POS + 1], r[PT_F_POS + 2], pt::filter_radius(r), tag, id, w);
+				ptl::pack_entry(r[PT_F_POS], r[PT_F_POS + 1], r[PT_F_POS + 2], radius, tag, id, w);
 				memcpy(entries.data() + (size_t)k * 4, w, 16);
 				all_listed &= tag >> 3;
 			}

@@ -54,8 +54,12 @@ __global__ __launch_bounds__(kBlock) void pt_k_grid_count(ptl::GridBuildJob job)
 	const uint32_t kind = type == PT_GEOM_SPHERE ? ((flags & 2) ? 0u : 3u) : type == PT_GEOM_BOX ? ((flags & 1) ? 2u : 1u) : type == PT_GEOM_CYLINDER ? 4u : type == PT_GEOM_CONE ? 5u : 6u;
 	job.obj_range[2 * (size_t)i] = (uint32_t)r.a[0] | ((uint32_t)r.a[1] << 10) | ((uint32_t)r.a[2] << 20) | ((kind & 3u) << 30);
 	job.obj_range[2 * (size_t)i + 1] = (uint32_t)r.b[0] | ((uint32_t)r.b[1] << 10) | ((uint32_t)r.b[2] << 20) | ((kind >> 2) << 30);
-	for(int z = r.a[2]; z <= r.b[2]; z++) for(int y = r.a[1]; y <= r.b[1]; y++) for(int x = r.a[0]; x <= r.b[0]; x++)
+	const float4 p = job.geo[(size_t)i * ptl::REC_STRIDE];
+	const float radius = job.bbox[i].w;
+	for(int z = r.a[2]; z <= r.b[2]; z++) for(int y = r.a[1]; y <= r.b[1]; y++) for(int x = r.a[0]; x <= r.b[0]; x++) {
+		if(job.cull && !ptl::reaches_cell(job.grid, p.x, p.y, p.z, radius, x, y, z)) continue;
 		atomicAdd(&job.cell_start[ptl::grid_cell(job.grid, x, y, z) + 1], 1u);
+	}
 }
 
 // Inclusive scan of kPerBlock values per block, in place; the block's total goes to totals[block].
@@ -123,7 +127,10 @@ __global__ __launch_bounds__(kBlock) void pt_k_grid_fill(ptl::GridBuildJob job) 
 	const int i = blockIdx.x * kBlock + threadIdx.x;
 	if(i >= job.n) return;
 	const CellRange r = range_of(job, i);
+	const float4 p = job.geo[(size_t)i * ptl::REC_STRIDE];
+	const float radius = job.bbox[i].w;
 	for(int z = r.a[2]; z <= r.b[2]; z++) for(int y = r.a[1]; y <= r.b[1]; y++) for(int x = r.a[0]; x <= r.b[0]; x++) {
+		if(job.cull && !ptl::reaches_cell(job.grid, p.x, p.y, p.z, radius, x, y, z)) continue;
 		const size_t c = ptl::grid_cell(job.grid, x, y, z);
 		job.cell_items[job.cell_start[c] + atomicAdd(&job.cursor[c], 1u)] = (uint32_t)i;
 	}
@@ -150,13 +157,18 @@ __global__ __launch_bounds__(kBlock) void pt_k_grid_order(ptl::GridBuildJob job,
 		const uint32_t id = list[k];
 		const uint32_t lo = job.obj_range[2 * (size_t)id], hi = job.obj_range[2 * (size_t)id + 1];
 		uint32_t tag = (lo >> 30) | ((hi >> 30) << 2);
-		for(int a = 0; a < 3; a++) {
-			if(at[a] > ((lo >> (10 * a)) & 1023u)) tag |= 1u << (3 + 2 * a);
-			if(at[a] < ((hi >> (10 * a)) & 1023u)) tag |= 1u << (4 + 2 * a);
-		}
 		const float4 p = job.geo[(size_t)id * ptl::REC_STRIDE];
+		const float radius = job.bbox[id].w;
+		for(int a = 0; a < 3; a++) {
+			// listed in the neighbour across this face: inside the entity's cell range, and not left out of that cell's list
+			int n[3] = { (int)at[0], (int)at[1], (int)at[2] };
+			n[a] = (int)at[a] - 1;
+			if(at[a] > ((lo >> (10 * a)) & 1023u) && (!job.cull || ptl::reaches_cell(job.grid, p.x, p.y, p.z, radius, n[0], n[1], n[2]))) tag |= 1u << (3 + 2 * a);
+			n[a] = (int)at[a] + 1;
+			if(at[a] < ((hi >> (10 * a)) & 1023u) && (!job.cull || ptl::reaches_cell(job.grid, p.x, p.y, p.z, radius, n[0], n[1], n[2]))) tag |= 1u << (4 + 2 * a);
+		}
 		uint32_t w[4];
-		ptl::pack_entry(p.x, p.y, p.z, job.bbox[id].w, tag, id, w);
+		ptl::pack_entry(p.x, p.y, p.z, radius, tag, id, w);
 		job.cell_entries[k] = make_float4(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]));
 		all_listed &= tag >> 3;
 	}

@@ -39,6 +39,26 @@ inline void grid_layout(GridDev& g) {
 	g.stride[axes[1]] = g.cnt[axes[0]];
 	g.stride[axes[2]] = g.cnt[axes[0]] * g.cnt[axes[1]];
 }
+// Whether an entity's own bounding sphere (centre p, radius r: pt::filter_radius) comes near the box of cell (x, y, z).  The
+// reference lists an entity in every cell its axis-aligned box covers (code/app.cpp:1297-1312), corners included that the
+// entity itself stays clear of; no hit point of the entity can lie in such a cell's box, so the reference, which accepts a hit
+// only inside the cell it is testing (code/raycast.cpp:957-983), never accepts one there, and a list without the entity gives
+// the same results with fewer entries to read.  The margin is a thousand times the rounding of a hit point.  Host and device
+// builds decide with these same float operations (no contraction in either).
+__host__ __device__ inline bool reaches_cell(const GridDev& g, float px, float py, float pz, float r, int x, int y, int z) {
+	const float p[3] = { px, py, pz };
+	const int c[3] = { x, y, z };
+	float dist2 = 0.0f, far = 0.0f;
+	for(int a = 0; a < 3; a++) {
+		const float lo = (float)((c[a] + g.cmin[a]) * g.cs[a]), hi = (float)((c[a] + g.cmin[a] + 1) * g.cs[a]);
+		const float d = p[a] < lo ? lo - p[a] : (p[a] > hi ? p[a] - hi : 0.0f);
+		dist2 = dist2 + d * d;
+		const float m = p[a] < 0.0f ? -p[a] : p[a];
+		far = m > far ? m : far;
+	}
+	const float reach = (r * 1.001f + 1e-3f) + 1e-5f * (far + r);
+	return !(dist2 > reach * reach);           // (an infinite radius - a plane - reaches everything)
+}
 inline bool grid_layout_is_reference(const GridDev& g) { return g.stride[0] == 1 && g.stride[1] == g.cnt[0] && g.stride[2] == g.cnt[0] * g.cnt[1]; }
 __host__ __device__ inline size_t grid_cell(const GridDev& g, int x, int y, int z) {
 	return (size_t)x * (size_t)g.stride[0] + (size_t)y * (size_t)g.stride[1] + (size_t)z * (size_t)g.stride[2];
@@ -193,6 +213,7 @@ struct GridBuildJob {
 	uint32_t* cell_items;       // out (second pass)
 	float4* cell_entries;       // out (second pass), may be null
 	uint32_t* longest;          // out: length of the longest list (one word)
+	int cull;                   // leave an entity out of the cells its own bounding sphere does not reach (reaches_cell)
 };
 size_t grid_scan_blocks(size_t cells);
 hipError_t launch_grid_count_scan(const GridBuildJob& job, size_t cells, hipStream_t stream);

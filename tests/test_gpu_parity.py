@@ -696,7 +696,7 @@ def test_cast_soak_first_scenes(gpu, seed):
 def test_grid_built_on_device_equals_host_build(gpu, name, monkeypatch):
     """The device passes (count, scan, fill, order) must give the host build's CSR word for word (ascending
     ids per cell, the reference's append order), the same packed cell ranges, and therefore the same image;
-    the host build itself is pinned to the reference's lists in the CPU tests."""
+    and both are the reference's lists (pinned in the CPU tests) less the entities that do not reach a cell."""
     if name == "dense30k":
         world, objs = scenes.dense_scene(n=30000, seed=11, half_extent=120.0, height=60.0)
         st = default_settings(96, 54, 4, 8, seed=77, grid_hint=40)
@@ -714,10 +714,36 @@ def test_grid_built_on_device_equals_host_build(gpu, name, monkeypatch):
     for a, b in zip(got["host"][:3], got["device"][:3]):
         assert a.shape == b.shape and (a == b).all()
     assert (bits(got["host"][3]) == bits(got["device"][3])).all()
+    # Against the reference's lists (the oracle's, pinned to the reference on the CPU): a cell's list here is the reference's list
+    # of that cell, in its order, less the entities that stay clear of the cell - every entity left out has its own bounding
+    # sphere (worked out here, in double precision, from the scene's description) wholly outside the cell's box.
     sc = OracleScene(world, objs, st)
-    _, cs, ci = sc.grid()
+    g, cs, ci = sc.grid()
     sc.close()
-    assert (cs == got["device"][0]).all() and (ci == got["device"][1]).all()
+    dev_start, dev_items = got["device"][0].astype(np.int64), got["device"][1]
+    assert dev_start.shape == cs.shape
+    cmin, cnt, size = np.array(g[0:3], np.float64), np.array(g[3:6], np.int64), np.array(g[6:9], np.float64)
+    half = np.array([[o.dim[0], o.dim[1], o.dim[2]] for o in objs], np.float64) / 2
+    pos = np.array([[o.pos[0], o.pos[1], o.pos[2]] for o in objs], np.float64)
+    kind = np.array([o.type for o in objs])
+    radius = np.where(kind == api.PT_GEOM_SPHERE, half.max(axis=1),
+                      np.where(kind == api.PT_GEOM_BOX, np.sqrt((half ** 2).sum(axis=1)), np.sqrt(np.maximum(half[:, 0], half[:, 1]) ** 2 + half[:, 2] ** 2)))
+    dropped = kept = 0
+    for cell in range(len(cs) - 1):
+        ref = ci[cs[cell]:cs[cell + 1]]
+        dev = dev_items[dev_start[cell]:dev_start[cell + 1]]
+        if len(ref) == len(dev):
+            assert (ref == dev).all()
+            kept += len(dev)
+            continue
+        assert np.isin(dev, ref).all() and (np.diff(dev.astype(np.int64)) > 0).all()
+        kept += len(dev)
+        lo = (np.array([cell % cnt[0], (cell // cnt[0]) % cnt[1], cell // (cnt[0] * cnt[1])], np.float64) + cmin) * size
+        for e in ref[~np.isin(ref, dev)]:
+            gap = np.maximum(np.maximum(lo - pos[e], 0.0), pos[e] - (lo + size))
+            assert np.sqrt((gap ** 2).sum()) > radius[e], (cell, int(e))
+            dropped += 1
+    assert kept == len(dev_items) and kept + dropped == len(ci)
 
 
 @pytest.mark.parametrize("w,h,spp", [(1, 1, 16), (8, 8, 4), (9, 17, 64), (24, 8, 4), (300, 7, 128)])
