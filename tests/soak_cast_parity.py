@@ -1,6 +1,7 @@
 """A longer run of the ray-cast comparison than the test suite holds: many random scenes, brute-force sized (3 to 9 entities,
 every ray tests every entity) and grid sized (20 to 120 entities), ids, hit positions and normals of the device against the
-oracle bit for bit.  From seed 1000 on every fourth scene also holds one to three planes (code/raycast.cpp:885-889, 937-955).  Not collected by pytest; run on the GPU box:  python tests/soak_cast_parity.py [first_seed] [scenes]"""
+oracle bit for bit.  From seed 1000 on every fourth scene also holds one to three planes (code/raycast.cpp:885-889, 937-955),
+and one scene in twenty-five has some thousand entities, enough for the grid to be built on the device.  Not collected by pytest; run on the GPU box:  python tests/soak_cast_parity.py [first_seed] [scenes]"""
 import ctypes as C
 import os
 import sys
@@ -43,6 +44,10 @@ for seed in range(first, first + count):
     world, objs = scenes.mixed_scene(seed=seed, n=n_obj, spread=6.0 + seed % 9)
     objs = with_planes(objs, seed)
     st = api.default_settings(64, 36, 4, 4, seed=4242, grid_hint=6 + seed % 7, brute_force_below=10)
+    if seed >= 1000 and seed % 25 == 7:
+        # now and then a scene large enough for the grid to be built on the device (4096 entities and more)
+        world, objs = scenes.dense_scene(n=4096 + (seed * 37) % 3000, seed=seed, half_extent=50.0 + seed % 30, height=20.0 + seed % 20)
+        st = api.default_settings(64, 36, 4, 4, seed=4242, grid_hint=16 + seed % 17, brute_force_below=10)
     gpu.prepare(world, objs, st)
     sc = OracleScene(world, objs, st)
     n = 20000
