@@ -856,6 +856,10 @@ static int cast_all(pto_scene* s, v3 rp, v3 rd, int outside, v3* ipos, v3* inrm)
 	return id;
 }
 
+/* Diagnosis: called for every hit the grid cast accepts as its best so far (entity, ray, hit point, distance). */
+static void (*g_hit_hook)(int, const float*, const float*, const float*, float) = 0;
+void pto_set_hit_hook(void (*hook)(int, const float*, const float*, const float*, float)) { g_hit_hook = hook; }
+
 static int cast_grid(pto_scene* s, v3 rp, v3 rd, v3* ipos, v3* inrm, uint64_t* hash) {
 	const grid_t* g = &s->grid;
 	walk_t w;
@@ -894,6 +898,7 @@ static int cast_grid(pto_scene* s, v3 rp, v3 rd, v3* ipos, v3* inrm, uint64_t* h
 				id = oi + 1;
 				*ipos = p;
 				*inrm = q;
+				if(g_hit_hook) g_hit_hook(oi, &rp.x, &rd.x, &p.x, distance);
 			}
 		}
 		if(id != 0) break;

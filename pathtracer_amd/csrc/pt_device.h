@@ -1392,13 +1392,21 @@ PT_MARK("trip_loaded");
 					const uint32_t tag = __float_as_uint(e[u].w);
 					PT_STAT(5, 1);
 					// an entity that is also listed in the cell the ray came from was collected there
+#ifndef PT_COOP_NO_DUP
 					const bool dup = (((tag >> 3) & 63u) >> ((who[u] >> 9) & 7u)) & 1u;        // face 7 (no previous cell) reads a zero bit
+#else
+					const bool dup = false;
+#endif
 					if(dup) PT_STAT(6, 1);
 					if(!dup) {
 						const V3 op = rop[u], od = rod[u];
 						v4f ball = e[u];                 // the id's bits move the centre by less than the radius was enlarged by
 						ball.w = __uint_as_float(tag & 0xffff0000u);
+#ifndef PT_COOP_NO_FILTER
 						if(!sphere_rejects(op, od, ball)) {
+#else
+						if(true) {
+#endif
 							uint32_t kind = tag & 7u;
 							const uint32_t id = ptl::entry_id(__float_as_uint(e[u].x), __float_as_uint(e[u].y), __float_as_uint(e[u].z), tag);
 							uint32_t slot = atomicAdd(&sh.count[KIND_COUNT], 1u);

@@ -28,7 +28,7 @@ struct CellRange { int a[3], b[3]; };
 
 __device__ __forceinline__ CellRange range_of(const ptl::GridBuildJob& job, int i) {
 	const float4 p = job.geo[(size_t)i * ptl::REC_STRIDE];          // position | bounding radius
-	const float4 box = job.bbox[i];
+	const float4 box = job.bbox[2 * (size_t)i];
 	const float pos[3] = { p.x, p.y, p.z }, dim[3] = { box.x, box.y, box.z };
 	CellRange r;
 	for(int k = 0; k < 3; k++) {
@@ -54,8 +54,8 @@ __global__ __launch_bounds__(kBlock) void pt_k_grid_count(ptl::GridBuildJob job)
 	const uint32_t kind = type == PT_GEOM_SPHERE ? ((flags & 2) ? 0u : 3u) : type == PT_GEOM_BOX ? ((flags & 1) ? 2u : 1u) : type == PT_GEOM_CYLINDER ? 4u : type == PT_GEOM_CONE ? 5u : 6u;
 	job.obj_range[2 * (size_t)i] = (uint32_t)r.a[0] | ((uint32_t)r.a[1] << 10) | ((uint32_t)r.a[2] << 20) | ((kind & 3u) << 30);
 	job.obj_range[2 * (size_t)i + 1] = (uint32_t)r.b[0] | ((uint32_t)r.b[1] << 10) | ((uint32_t)r.b[2] << 20) | ((kind >> 2) << 30);
-	const float4 p = job.geo[(size_t)i * ptl::REC_STRIDE];
-	const float radius = job.bbox[i].w;
+	const float4 p = job.bbox[2 * (size_t)i + 1];              // the filter sphere's centre
+	const float radius = job.bbox[2 * (size_t)i].w;
 	for(int z = r.a[2]; z <= r.b[2]; z++) for(int y = r.a[1]; y <= r.b[1]; y++) for(int x = r.a[0]; x <= r.b[0]; x++) {
 		if(job.cull && !ptl::reaches_cell(job.grid, p.x, p.y, p.z, radius, x, y, z)) continue;
 		atomicAdd(&job.cell_start[ptl::grid_cell(job.grid, x, y, z) + 1], 1u);
@@ -127,8 +127,8 @@ __global__ __launch_bounds__(kBlock) void pt_k_grid_fill(ptl::GridBuildJob job) 
 	const int i = blockIdx.x * kBlock + threadIdx.x;
 	if(i >= job.n) return;
 	const CellRange r = range_of(job, i);
-	const float4 p = job.geo[(size_t)i * ptl::REC_STRIDE];
-	const float radius = job.bbox[i].w;
+	const float4 p = job.bbox[2 * (size_t)i + 1];
+	const float radius = job.bbox[2 * (size_t)i].w;
 	for(int z = r.a[2]; z <= r.b[2]; z++) for(int y = r.a[1]; y <= r.b[1]; y++) for(int x = r.a[0]; x <= r.b[0]; x++) {
 		if(job.cull && !ptl::reaches_cell(job.grid, p.x, p.y, p.z, radius, x, y, z)) continue;
 		const size_t c = ptl::grid_cell(job.grid, x, y, z);
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(kBlock) void pt_k_grid_order(ptl::GridBuildJob job,
 		const uint32_t id = list[k];
 		const uint32_t lo = job.obj_range[2 * (size_t)id], hi = job.obj_range[2 * (size_t)id + 1];
 		uint32_t tag = (lo >> 30) | ((hi >> 30) << 2);
-		const float4 p = job.geo[(size_t)id * ptl::REC_STRIDE];
-		const float radius = job.bbox[id].w;
+		const float4 p = job.bbox[2 * (size_t)id + 1];
+		const float radius = job.bbox[2 * (size_t)id].w;
 		for(int a = 0; a < 3; a++) {
 			// listed in the neighbour across this face: inside the entity's cell range, and not left out of that cell's list
 			int n[3] = { (int)at[0], (int)at[1], (int)at[2] };

@@ -395,6 +395,35 @@ float filter_radius(const float* record) {
 	return record[PT_F_BRADIUS];
 }
 
+// A sphere that encloses the entity, not necessarily about its position, for the same filter and for leaving entities out of
+// the cells they stay clear of.  A cone (apex at +dz/2 on its own z axis, base of semi-axes dx/2, dy/2 at -dz/2:
+// code/raycast.cpp:352-388 in unit space) fits a sphere through its apex and the rim of its base - or, when it is flatter
+// than wide, the sphere about the base's centre with the rim's radius: for a cone twice as high as its base radius 1.25
+// radii about a point a quarter of the height below the middle, instead of 1.41 about the middle.  Every other kind is
+// symmetric about its position.
+float filter_sphere(const float* record, float centre[3]) {
+	centre[0] = record[PT_F_POS]; centre[1] = record[PT_F_POS + 1]; centre[2] = record[PT_F_POS + 2];
+	int32_t type;
+	memcpy(&type, record + PT_F_TYPE, 4);
+#ifndef PT_LOOSE_FILTER_RADIUS
+	if(type == PT_GEOM_CONE) {
+		const double rim = (double)tmax(record[PT_F_DIM], record[PT_F_DIM + 1]) * 0.5, height = (double)record[PT_F_DIM + 2];
+		if(!(rim > 0.0) || !(height > 0.0) || !std::isfinite(rim) || !std::isfinite(height)) return filter_radius(record);
+		const double above_base = height > rim ? (height * height - rim * rim) / (2.0 * height) : 0.0;
+		const double radius = height > rim ? (height * height + rim * rim) / (2.0 * height) : rim;
+		// the cone's axis in the world: the rotation applied to (0, 0, 1) (Quat * Vec3, code/rt_math.cpp:2902-2907)
+		const double w = record[PT_F_ROT], x = record[PT_F_ROT + 1], y = record[PT_F_ROT + 2], z = record[PT_F_ROT + 3];
+		if(!(fabs(w * w + x * x + y * y + z * z - 1.0) < 1e-4)) return filter_radius(record);      // not a rotation: no better than before
+		const double axis[3] = { 2.0 * (x * z + w * y), 2.0 * (y * z - w * x), 1.0 - 2.0 * (x * x + y * y) };
+		const double along = above_base - height * 0.5;
+		for(int a = 0; a < 3; a++) centre[a] = (float)((double)centre[a] + axis[a] * along);
+		// rounded up: the centre's own rounding, a quaternion not quite of unit length, the arithmetic above
+		return (float)(radius * 1.00001 + 1e-6 * (fabs((double)centre[0]) + fabs((double)centre[1]) + fabs((double)centre[2])));
+	}
+#endif
+	return filter_radius(record);
+}
+
 // ---- screenshot encoding (code/app.cpp:1541-1547) ------------------------------------------------------
 uint8_t srgb8_encode(float v) {
 	if(v < 0.0031308f) v *= 12.92f;

@@ -55,6 +55,8 @@ bool object_ranges(const float* records, int n, const GridDesc& g, std::vector<u
 void plane_normal(const float* record, float out[3]);
 // Radius of a sphere about the entity's position that encloses it (the cooperative cast's conservative filter); infinite for a plane.
 float filter_radius(const float* record);
+// The same with a centre of its own: a cone's smallest enclosing sphere sits below the entity's position, towards the base.
+float filter_sphere(const float* record, float centre[3]);
 
 // Screenshot encoding of one channel (floatToSrgb then colorFloatToInt, code/rt_math.cpp:3634-3640,351-353, as
 // code/app.cpp:1544 combines them) and the 255 smallest inputs in [0, 1] at which its output steps up to

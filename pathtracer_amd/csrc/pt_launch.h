@@ -39,12 +39,13 @@ inline void grid_layout(GridDev& g) {
 	g.stride[axes[1]] = g.cnt[axes[0]];
 	g.stride[axes[2]] = g.cnt[axes[0]] * g.cnt[axes[1]];
 }
-// Whether an entity's own bounding sphere (centre p, radius r: pt::filter_radius) comes near the box of cell (x, y, z).  The
+// Whether an entity's own bounding sphere (centre p, radius r: pt::filter_sphere) comes near the box of cell (x, y, z).  The
 // reference lists an entity in every cell its axis-aligned box covers (code/app.cpp:1297-1312), corners included that the
-// entity itself stays clear of; no hit point of the entity can lie in such a cell's box, so the reference, which accepts a hit
-// only inside the cell it is testing (code/raycast.cpp:957-983), never accepts one there, and a list without the entity gives
-// the same results with fewer entries to read.  The margin is a thousand times the rounding of a hit point.  Host and device
-// builds decide with these same float operations (no contraction in either).
+// entity itself stays clear of.  Lists without such entries (the optional cell cull, and the neighbour bits that go with it)
+// are shorter, but not equivalent: the reference accepts a hit in the listed cell that holds the COMPUTED hit point
+// (code/raycast.cpp:957-983), and a point computed from far away or at a grazing angle lies some way along the ray from the
+// true surface, now and then in a cell the entity does not reach.  Host and device builds decide with these same float
+// operations (no contraction in either).
 __host__ __device__ inline bool reaches_cell(const GridDev& g, float px, float py, float pz, float r, int x, int y, int z) {
 	const float p[3] = { px, py, pz };
 	const int c[3] = { x, y, z };
@@ -203,7 +204,8 @@ hipError_t launch_assemble(const float* parts, size_t stride, int part_count, in
 // Device-side grid build (pt_gridbuild.hip).
 struct GridBuildJob {
 	const float4* geo;          // entity records (position | bounding radius in slot 0, type + flags in slot 3)
-	const float4* bbox;         // world-space bounding-box extents of every entity | radius of the sphere the cooperative cast's filter tests
+	const float4* bbox;         // two per entity: world-space bounding-box extents | radius of the sphere the cooperative cast's filter tests,
+	                            // that sphere's centre (the entity's position, except for a cone: pt::filter_sphere) | 0
 	int n;
 	GridDev grid;
 	uint32_t* obj_range;        // out: 2 words per entity
