@@ -320,8 +320,10 @@ int prepare(pt_ctx* c) {
 
 	// one 128-byte record of eight float4 per entity (layout documented in pt_device.h)
 	const size_t np = (size_t)(n > 0 ? n : 1);
-	std::vector<float> geo(np * ptl::REC_STRIDE * 4, 0.0f);
-	int features = 0;          // what the entities need of a kernel variant: 1 unit-space kinds, 2 glass, 4 roughness, 8 planes (FEAT_* in pt_device.h)
+	// ... and behind the records two more float4 per entity, read for cones only, by the trace variants that reproduce the
+	// reference cone intersector's phantom hits (pt::cone_slopes)
+	std::vector<float> geo(np * (ptl::REC_STRIDE + 2) * 4, 0.0f);
+	int features = 0;          // what the entities need of a kernel variant: 1 unit-space kinds, 2 glass, 4 roughness, 8 planes (FEAT_* in pt_device.h), 32 cones
 	std::vector<uint32_t> plane_ids;
 	for(int i = 0; i < n; i++) {
 		const float* r = rec.data() + (size_t)i * PT_F_STRIDE;
@@ -363,6 +365,10 @@ int prepare(pt_ctx* c) {
 		}
 		float* m0 = slot(ptl::REC_COLOR); m0[0] = r[PT_F_COLOR]; m0[1] = r[PT_F_COLOR + 1]; m0[2] = r[PT_F_COLOR + 2]; m0[3] = r[PT_F_REFL];
 		float* m1 = slot(ptl::REC_EMIT); m1[0] = r[PT_F_EMIT]; m1[1] = r[PT_F_EMIT + 1]; m1[2] = r[PT_F_EMIT + 2]; m1[3] = r[PT_F_IOR];
+		if(type == PT_GEOM_CONE) {
+			features |= 32;
+			pt::cone_slopes(r, geo.data() + (np * ptl::REC_STRIDE + 2 * (size_t)i) * 4);
+		}
 	}
 
 	int rc;

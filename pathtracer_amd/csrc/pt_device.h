@@ -1174,7 +1174,8 @@ PT_DEV void coop_lane_reset(CoopLane& st) { st.walking = false; }
 // it was in.  The call returns as soon as fewer than COOP_MIN_WALKING lanes are still walking, so
 // the caller can shade the finished rays and hand their lanes new ones instead of idling them until
 // the longest walk of the wavefront ends; `done` tells which lanes have their result.
-template <int FEAT>
+// CONES: also the reference cone intersector's phantom hits, which the bounding-sphere filter otherwise drops (in the expand step).
+template <int FEAT, bool CONES = false>
 PT_DEV int cast_grid_coop(const Scene& sc, CoopShared& sh, int lane, bool active, bool fresh, CoopLane& st, V3 rp, V3 rd, V3& hpos,
                           V3& hnrm, Surface& surf, bool& done) {
 	int result = 0;
@@ -1403,7 +1404,20 @@ PT_MARK("trip_loaded");
 						v4f ball = e[u];                 // the id's bits move the centre by less than the radius was enlarged by
 						ball.w = __uint_as_float(tag & 0xffff0000u);
 #ifndef PT_COOP_NO_FILTER
-						if(!sphere_rejects(op, od, ball)) {
+						bool keep = !sphere_rejects(op, od, ball);
+						// CONES: a cone the ray stays clear of is still a candidate when the ray runs parallel to one of its generators - the
+						// reference's intersector then divides by a rounded zero and reports a hit where the ray crosses the base plane
+						// (pt::cone_slopes has the formula and the two float4 behind the entity records that this reads).
+						if(CONES && !keep && (tag & 7u) == (uint32_t)KIND_CONE) {
+							const uint32_t id = ptl::entry_id(__float_as_uint(e[u].x), __float_as_uint(e[u].y), __float_as_uint(e[u].z), tag);
+							cf4 slopes = sc.geo + ((size_t)sc.n * G_SLOTS + 2 * (size_t)id);
+							const v4f s0 = slopes[0], s1 = slopes[1];
+							const float ax = fdot(od, v3(s0.x, s0.y, s0.z)), az = fdot(od, v3(s1.x, s1.y, s1.z));
+							const float px = ax * ax, pz = az * az;
+							const float a = __builtin_fmaf(s0.w, px, __builtin_fmaf(s1.w, fdot(od, od) - pz, -pz));
+							keep = !(__builtin_fabsf(a) >= 0.02f * __builtin_fmaf(2.0f, pz, a));
+						}
+						if(keep) {
 #else
 						if(true) {
 #endif

@@ -424,6 +424,34 @@ float filter_sphere(const float* record, float centre[3]) {
 	return filter_radius(record);
 }
 
+// The reference's cone intersector divides by a = dx^2 + dy^2 - dz^2 of the ray's normalised direction in the cone's unit space
+// (code/raycast.cpp:352-388).  For a ray parallel to one of the cone's generators a rounds to zero or next to it: one root is
+// then NaN or garbage, the other is replaced by the ray's crossing of the base plane, and that point - anywhere on the plane -
+// comes back as the hit.  No bounding volume of the cone holds such a ray; a cast that filters by bounding volume and wants
+// these hits too has to let the cone through by the ray's direction d.  With ex, ey, ez the cone's axes in the world and
+// A = 4/dx^2, B = 4/dy^2, C = 1/dz^2, a is (A (d.ex)^2 + B (d.ey)^2 - C (d.ez)^2) / (A (d.ex)^2 + B (d.ey)^2 + C (d.ez)^2), and
+// (d.ey)^2 is |d|^2 less the other two squares.  out[0..2] = ex, out[3] = (A - B) / C, out[4..6] = ez, out[7] = B / C; the device
+// keeps the cone when |a| < 0.02 (a root goes astray by about 1e-7 t / |a| of the ray's length t; the filter's own margins cover
+// a hundred times that at 0.02).  A record the formula does not fit (a rotation not of unit length, an extent of zero) gets
+// NaNs: every ray keeps it.
+void cone_slopes(const float* record, float out[8]) {
+	const double w = record[PT_F_ROT], x = record[PT_F_ROT + 1], y = record[PT_F_ROT + 2], z = record[PT_F_ROT + 3];
+	const double len2 = w * w + x * x + y * y + z * z;
+	const double dx = record[PT_F_DIM], dy = record[PT_F_DIM + 1], dz = record[PT_F_DIM + 2];
+	const bool fits = fabs(len2 - 1.0) < 1e-3 && std::isfinite(dx) && std::isfinite(dy) && std::isfinite(dz) && dx != 0.0 && dy != 0.0 && dz != 0.0;
+	if(!fits) {
+		for(int k = 0; k < 8; k++) out[k] = NAN;
+		return;
+	}
+	// rot * (1, 0, 0) and rot * (0, 0, 1) (Quat * Vec3, code/rt_math.cpp:2902-2907)
+	const double ex[3] = { 1.0 - 2.0 * (y * y + z * z), 2.0 * (x * y + w * z), 2.0 * (x * z - w * y) };
+	const double ez[3] = { 2.0 * (x * z + w * y), 2.0 * (y * z - w * x), 1.0 - 2.0 * (x * x + y * y) };
+	const double A = 4.0 / (dx * dx), B = 4.0 / (dy * dy), C = 1.0 / (dz * dz);
+	for(int k = 0; k < 3; k++) { out[k] = (float)ex[k]; out[4 + k] = (float)ez[k]; }
+	out[3] = (float)((A - B) / C);
+	out[7] = (float)(B / C);
+}
+
 // ---- screenshot encoding (code/app.cpp:1541-1547) ------------------------------------------------------
 uint8_t srgb8_encode(float v) {
 	if(v < 0.0031308f) v *= 12.92f;

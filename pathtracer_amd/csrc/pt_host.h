@@ -57,6 +57,9 @@ void plane_normal(const float* record, float out[3]);
 float filter_radius(const float* record);
 // The same with a centre of its own: a cone's smallest enclosing sphere sits below the entity's position, towards the base.
 float filter_sphere(const float* record, float centre[3]);
+// What tells whether a ray's direction is parallel, or nearly, to one of a cone's generators: two of the cone's axes in the world
+// and two ratios of its squared extents (eight floats; pt_host.cpp has the formula).
+void cone_slopes(const float* record, float out[8]);
 
 // Screenshot encoding of one channel (floatToSrgb then colorFloatToInt, code/rt_math.cpp:3634-3640,351-353, as
 // code/app.cpp:1544 combines them) and the 255 smallest inputs in [0, 1] at which its output steps up to

@@ -119,7 +119,7 @@ struct SceneDev {
 	int n;
 	int brute;
 	int coop;                   // 1: the wave-cooperative cast may be used (ranges fit their packing)
-	int features;               // FEAT_* bits (pt_device.h) of what the entities need: unit-space kinds, glass, roughness, planes
+	int features;               // FEAT_* bits (pt_device.h) of what the entities need: unit-space kinds, glass, roughness, planes; 32: there are cones
 	GridDev grid;
 };
 
@@ -175,7 +175,7 @@ struct TraceJob {
 
 // What a launch of the persistent trace kernel needs to know of the device: filled once per context, under that
 // context's device (compute units, resident workgroups per unit of each kernel variant).
-constexpr int kTraceVariants = 8;
+constexpr int kTraceVariants = 10;
 struct TraceCaps { int cus; int blocks_per_cu[kTraceVariants]; };
 hipError_t query_trace_caps(TraceCaps* caps);
 hipError_t launch_trace(const TraceJob& job, const TraceCaps& caps, hipStream_t stream, int* grid_blocks_out);

@@ -1,9 +1,10 @@
 """Longer run than the test suite wants (not collected by pytest): whole frames of random scenes above the brute-force
 threshold, every pixel against the oracle's frame (sixteen host threads).  Scenes without rough entities must be the
-oracle's bits but for pixels where the oracle accepted a hit that the cooperative cast's bounding-sphere filter turns
-away - and each of those must be a cone hit by a ray parallel to one of its generators (the reference intersector's
-phantom hit; how many there are depends on the scene's cones and is reported, not judged); scenes with rough entities
-must stay within the radiance tolerance apart from such pixels.
+oracle's bits, scenes with rough entities within the radiance tolerance, every pixel.
+With PT_FAST_CONES=1 (the cooperative cast's plain variants also for scenes with cones) pixels may be off where the
+oracle accepted a hit that the bounding-sphere filter turns away - and each of those must be a cone hit by a ray parallel
+to one of its generators (the reference intersector's phantom hit; how many there are depends on the scene's cones and is
+reported, not judged).
 usage: python tests/soak_whole_frames.py [first_seed [count]]"""
 import os, sys, time
 import numpy as np
@@ -58,7 +59,7 @@ for seed in range(first, first + count):
             explained += 1 if cone_only else 0
             if say or not cone_only:
                 print("   pixel", p, "explained" if cone_only else "UNEXPLAINED", hits, flush=True)
-        ok = ok and explained == min(len(pixels), 40)
+        ok = ok and explained == min(len(pixels), 40) and bool(os.environ.get("PT_FAST_CONES"))
     total_pixels += fin.size
     total_differ += len(pixels)
     bad += 0 if ok else 1

@@ -593,9 +593,7 @@ def test_whole_grid_frames_against_the_oracle(gpu, name):
     """Every pixel of the glass frame at full size and of the 100 000-entity frame at 1080p / 128 spp against the oracle's
     whole frame (sixteen host threads, 12 and 19 seconds).  The glass frame, whose entities are rough, within the radiance
     tolerance everywhere (the largest relative error seen is 3e-7: libm against the device's own powf and acosf).  The
-    100 000-entity frame bit for bit, but for an epsilon-edge share of pixels (two of two million) where the reference's
-    cone intersector reports a phantom hit on the cone's base plane for a ray parallel to a generator
-    (test_whole_frames_cooperative_cast_against_per_lane_walk says how) and the cooperative cast's filter has dropped it."""
+    100 000-entity frame bit for bit."""
     import bench
     world, objs, kw = bench.workload(name)
     st = default_settings(kw.pop("width"), kw.pop("height"), kw.pop("spp"), kw.pop("bounces"), **kw)
@@ -609,7 +607,7 @@ def test_whole_grid_frames_against_the_oracle(gpu, name):
     assert (np.isfinite(img).all(axis=2) == fin).all() and (~fin).mean() <= EDGE_FRACTION
     if all(o.roughness == 0.0 for o in objs):
         differ = (bits(img) != bits(ref)).any(axis=2) & fin
-        assert differ.mean() <= EDGE_FRACTION, f"{int(differ.sum())} pixels differ"
+        assert not differ.any(), f"{int(differ.sum())} pixels differ"
     else:
         e = rel_err(img[fin], ref[fin])
         assert (e > REL_TOL).sum() <= max(1, int(EDGE_FRACTION * e.size) + 1)
@@ -722,31 +720,39 @@ def test_grid_scenes_at_full_size(gpu, name):
     assert (same | ~np.isfinite(a)).all(), "the eight-partition frame differs from the one-partition frame"
 
 
-@pytest.mark.parametrize("name", ["dense100k-4k-256spp-d8", "glass-1080p-128spp-d32"])
-def test_whole_frames_cooperative_cast_against_per_lane_walk(gpu, name, tmp_path):
-    """Every pixel of the two grid frames at full size, rendered by the cooperative cast (the default) and by the per-lane
-    grid walk (PT_GRID_PER_LANE=1, read once per process: a child process renders it) - two implementations of the
-    reference's traversal that share the intersectors and nothing else.  They may differ in an epsilon-edge share of the
-    pixels only, and where they do the per-lane walk must be the oracle's pixel: the reference's cone intersector
-    divides by dx^2 + dy^2 - dz^2 of the ray's unit-space direction (code/raycast.cpp:352-388), which rounds to zero for
-    a ray parallel to one of the cone's generators; one root is then NaN or garbage, the other is replaced by the
-    crossing of the base plane, and the cast accepts that point - up to a cell away from the cone - when it lies in a
-    cell that lists the cone.  The cooperative cast's bounding-sphere filter has turned such a ray away before the
-    intersector sees it (12 of 8.3 million pixels of the 100 000-entity frame; none of the glass frame)."""
+def _frame_in_a_child_process(name, path, **env):
+    """One whole frame of a benchmark workload rendered by a child process under environment switches of the library (they
+    are read once per process)."""
     import subprocess
     import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    subprocess.run([sys.executable, "-u", os.path.join(here, "diag_frames.py"), "render", name, str(path)], env=dict(os.environ, **env), check=True, timeout=300)
+    return np.load(str(path))
+
+
+@pytest.mark.parametrize("name", ["dense100k-4k-256spp-d8", "glass-1080p-128spp-d32"])
+def test_whole_frames_cooperative_cast_against_per_lane_walk(gpu, name, tmp_path):
+    """Every pixel of the two grid frames at full size, rendered by the cooperative cast and by the per-lane grid walk
+    (PT_GRID_PER_LANE=1, read once per process: a child process renders it) - two implementations of the reference's
+    traversal that share the intersectors and nothing else: the same bits, every pixel.
+    The cooperative cast's plain variants (a scene without cones runs them; PT_FAST_CONES=1 forces them) may differ in an
+    epsilon-edge share of the pixels, and where they do the per-lane walk must be the oracle's pixel: the reference's cone
+    intersector divides by dx^2 + dy^2 - dz^2 of the ray's unit-space direction (code/raycast.cpp:352-388), which rounds to
+    zero for a ray parallel to one of the cone's generators; one root is then NaN or garbage, the other is replaced by the
+    crossing of the base plane, and the cast accepts that point - up to a cell away from the cone - when it lies in a cell
+    that lists the cone.  The plain variants' bounding-sphere filter has turned such a ray away before the intersector
+    sees it (12 of 8.3 million pixels of the 100 000-entity frame; none of the glass frame); the variants a scene with
+    cones runs by default let it through by its direction."""
     import bench
     world, objs, kw = bench.workload(name)
     st = default_settings(kw.pop("width"), kw.pop("height"), kw.pop("spp"), kw.pop("bounces"), **kw)
     a = gpu.render(world, objs, st)
-    out = str(tmp_path / "lane.npy")
-    env = dict(os.environ, PT_GRID_PER_LANE="1")
-    here = os.path.dirname(os.path.abspath(__file__))
-    subprocess.run([sys.executable, "-u", os.path.join(here, "diag_frames.py"), "render", name, out], env=env, check=True, timeout=300)
-    b = np.load(out)
+    b = _frame_in_a_child_process(name, tmp_path / "lane.npy", PT_GRID_PER_LANE="1")
     assert a.shape == b.shape
-    differ = (bits(a) != bits(b)).any(axis=2)
-    assert differ.mean() <= EDGE_FRACTION, f"{int(differ.sum())} pixels differ"
+    assert (bits(a) == bits(b)).all(), f"{int((bits(a) != bits(b)).any(axis=2).sum())} pixels differ"
+    c = _frame_in_a_child_process(name, tmp_path / "fast.npy", PT_FAST_CONES="1")
+    differ = (bits(c) != bits(b)).any(axis=2)
+    assert differ.mean() <= EDGE_FRACTION, f"{int(differ.sum())} pixels differ with PT_FAST_CONES=1"
     if differ.any():
         assert any(o.type == api.PT_GEOM_CONE for o in objs)
         sc = OracleScene(world, objs, st)
