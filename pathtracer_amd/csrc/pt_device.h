@@ -1386,6 +1386,10 @@ PT_MARK("trip_ranked");
 			PT_TOCK_ISSUED(sh, 11, t0);
 			PT_TOCK_LANDED(sh, 8, t0);
 PT_MARK("trip_loaded");
+			bool cone_need[COOP_ITEMS];               // CONES: the item is a cone that the sphere test turned away
+			uint32_t cone_id[COOP_ITEMS];
+			#pragma unroll
+			for(int u = 0; u < COOP_ITEMS; u++) { cone_need[u] = false; cone_id[u] = 0; }
 			#pragma unroll
 			for(int u = 0; u < COOP_ITEMS; u++) {
 				if(live[u]) {
@@ -1404,18 +1408,11 @@ PT_MARK("trip_loaded");
 						v4f ball = e[u];                 // the id's bits move the centre by less than the radius was enlarged by
 						ball.w = __uint_as_float(tag & 0xffff0000u);
 #ifndef PT_COOP_NO_FILTER
-						bool keep = !sphere_rejects(op, od, ball);
-						// CONES: a cone the ray stays clear of is still a candidate when the ray runs parallel to one of its generators - the
-						// reference's intersector then divides by a rounded zero and reports a hit where the ray crosses the base plane
-						// (pt::cone_slopes has the formula and the two float4 behind the entity records that this reads).
+						const bool keep = !sphere_rejects(op, od, ball);
+						// CONES: a cone the ray stays clear of is looked at once more, below
 						if(CONES && !keep && (tag & 7u) == (uint32_t)KIND_CONE) {
-							const uint32_t id = ptl::entry_id(__float_as_uint(e[u].x), __float_as_uint(e[u].y), __float_as_uint(e[u].z), tag);
-							cf4 slopes = sc.geo + ((size_t)sc.n * G_SLOTS + 2 * (size_t)id);
-							const v4f s0 = slopes[0], s1 = slopes[1];
-							const float ax = fdot(od, v3(s0.x, s0.y, s0.z)), az = fdot(od, v3(s1.x, s1.y, s1.z));
-							const float px = ax * ax, pz = az * az;
-							const float a = __builtin_fmaf(s0.w, px, __builtin_fmaf(s1.w, fdot(od, od) - pz, -pz));
-							keep = !(__builtin_fabsf(a) >= 0.02f * __builtin_fmaf(2.0f, pz, a));
+							cone_need[u] = true;
+							cone_id[u] = ptl::entry_id(__float_as_uint(e[u].x), __float_as_uint(e[u].y), __float_as_uint(e[u].z), tag);
 						}
 						if(keep) {
 #else
@@ -1427,6 +1424,36 @@ PT_MARK("trip_loaded");
 							atomicAdd(&sh.count[kind], 1u);
 							sh.pool[slot] = ((uint32_t)owner << 26) | (kind << 23) | id;
 						} else PT_STAT(7, 1);
+					}
+				}
+			}
+			// CONES: a cone the ray stays clear of is still a candidate when the ray runs parallel to one of its generators - the
+			// reference's intersector then divides by a rounded zero and reports a hit where the ray crosses the base plane
+			// (pt::cone_slopes has the formula and the two float4 behind the entity records that this reads).  Both items' words
+			// are asked for before either is looked at: one wait per trip.
+			if constexpr (CONES) {
+				bool any = false;
+				#pragma unroll
+				for(int u = 0; u < COOP_ITEMS; u++) any = any || cone_need[u];
+				if(any) {
+					v4f s0[COOP_ITEMS], s1[COOP_ITEMS];
+					#pragma unroll
+					for(int u = 0; u < COOP_ITEMS; u++) {
+						cf4 slopes = sc.geo + ((size_t)sc.n * G_SLOTS + 2 * (size_t)cone_id[u]);      // (entity 0's when the item needs none: any valid address)
+						s0[u] = slopes[0];
+						s1[u] = slopes[1];
+					}
+					#pragma unroll
+					for(int u = 0; u < COOP_ITEMS; u++) {
+						const V3 od = rod[u];
+						const float ax = fdot(od, v3(s0[u].x, s0[u].y, s0[u].z)), az = fdot(od, v3(s1[u].x, s1[u].y, s1[u].z));
+						const float px = ax * ax, pz = az * az;
+						const float a = __builtin_fmaf(s0[u].w, px, __builtin_fmaf(s1[u].w, fdot(od, od) - pz, -pz));
+						if(cone_need[u] && !(__builtin_fabsf(a) >= 0.02f * __builtin_fmaf(2.0f, pz, a))) {
+							uint32_t slot = atomicAdd(&sh.count[KIND_COUNT], 1u);
+							atomicAdd(&sh.count[KIND_CONE], 1u);
+							sh.pool[slot] = ((who[u] & 63u) << 26) | ((uint32_t)KIND_CONE << 23) | cone_id[u];
+						}
 					}
 				}
 			}
