@@ -20,16 +20,19 @@ gpu = api.Renderer(0)
 bad = 0
 total_pixels = total_differ = 0
 for seed in range(first, first + count):
-    kind = seed % 3
+    kind = seed % 4
     if kind == 0:
         world, objs = scenes.mixed_scene(seed=seed, n=20 + (seed * 7) % 101, rough_share=0.0, spread=8.0 + seed % 13)
         st = api.default_settings(960, 540, 32, 8 + seed % 9, seed=1000 + seed, grid_hint=6 + seed % 7, brute_force_below=10)
     elif kind == 1:
         world, objs = scenes.dense_scene(n=3000 + (seed * 977) % 20000, seed=seed, half_extent=60.0 + seed % 50, height=30.0)
         st = api.default_settings(960, 540, 32, 8, seed=1000 + seed, grid_hint=16 + seed % 24)
-    else:
+    elif kind == 2:
         world, objs = scenes.mixed_scene(seed=seed, n=20 + (seed * 7) % 101, spread=8.0 + seed % 13)
         st = api.default_settings(960, 540, 16, 8 + seed % 9, seed=1000 + seed, grid_hint=6 + seed % 7, brute_force_below=10)
+    else:
+        world, objs = scenes.planes_grid_scene(seed=seed, n=20 + (seed * 5) % 90)        # three planes among every kind and material
+        st = api.default_settings(960, 540, 16, 8 + seed % 5, seed=1000 + seed, grid_hint=6 + seed % 7, brute_force_below=10)
     t0 = time.time()
     img = gpu.render(world, objs, st)
     sc = OracleScene(world, objs, st)
