@@ -432,8 +432,8 @@ float filter_sphere(const float* record, float centre[3]) {
 // A = 4/dx^2, B = 4/dy^2, C = 1/dz^2, a is (A (d.ex)^2 + B (d.ey)^2 - C (d.ez)^2) / (A (d.ex)^2 + B (d.ey)^2 + C (d.ez)^2), and
 // (d.ey)^2 is |d|^2 less the other two squares.  out[0..2] = ex, out[3] = (A - B) / C, out[4..6] = ez, out[7] = B / C; the device
 // keeps the cone when |a| < 0.02 (a root goes astray by about 1e-7 t / |a| of the ray's length t; the filter's own margins cover
-// a hundred times that at 0.02).  A record the formula does not fit (a rotation not of unit length, an extent of zero) gets
-// NaNs: every ray keeps it.
+// a hundred times that at 0.02).  A record the formula does not fit (a rotation not of unit length, an extent of zero, extreme
+// proportions) gets NaNs: every ray keeps it.
 void cone_slopes(const float* record, float out[8]) {
 	const double w = record[PT_F_ROT], x = record[PT_F_ROT + 1], y = record[PT_F_ROT + 2], z = record[PT_F_ROT + 3];
 	const double len2 = w * w + x * x + y * y + z * z;
@@ -447,6 +447,12 @@ void cone_slopes(const float* record, float out[8]) {
 	const double ex[3] = { 1.0 - 2.0 * (y * y + z * z), 2.0 * (x * y + w * z), 2.0 * (x * z - w * y) };
 	const double ez[3] = { 2.0 * (x * z + w * y), 2.0 * (y * z - w * x), 1.0 - 2.0 * (x * x + y * y) };
 	const double A = 4.0 / (dx * dx), B = 4.0 / (dy * dy), C = 1.0 / (dz * dz);
+	// The device forms (d.ex)^2 + (d.ey)^2 as |d|^2 - (d.ez)^2, which loses about 6e-8 |d|^2: times a ratio of a thousand that is
+	// still three hundred times below the tolerance.  A needle of a cone (its height more than fifteen base diameters) gets NaNs too.
+	if(!(fabs((A - B) / C) < 1e3 && B / C < 1e3)) {
+		for(int k = 0; k < 8; k++) out[k] = NAN;
+		return;
+	}
 	for(int k = 0; k < 3; k++) { out[k] = (float)ex[k]; out[4 + k] = (float)ez[k]; }
 	out[3] = (float)((A - B) / C);
 	out[7] = (float)(B / C);

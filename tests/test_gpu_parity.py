@@ -614,6 +614,29 @@ def test_whole_grid_frames_against_the_oracle(gpu, name):
         assert np.abs(img[fin].astype(np.float64) - ref[fin]).mean() < 1e-6
 
 
+def test_cones_of_extreme_proportions(gpu):
+    """Needles, discs and lopsided cones among a grid scene's entities: the direction test that lets a cone past the bounding-sphere
+    filter gives such a cone no data (every ray keeps it), and the frame is the oracle's, bit for bit."""
+    world, objs = scenes.mixed_scene(seed=21, n=36, rough_share=0.0, spread=10.0)
+    rng = np.random.default_rng(5)
+    for k, dim in enumerate([(0.05, 0.05, 6.0), (0.3, 0.3, 9.0), (6.0, 6.0, 0.02), (5.0, 0.04, 2.0), (0.04, 5.0, 2.0), (1e-3, 1e-3, 3.0), (3.0, 3.0, 3.0)]):
+        q = rng.normal(size=4)
+        q = q / np.linalg.norm(q)
+        rot = (1, 0, 0, 0) if k % 3 == 0 else tuple(float(v) for v in q)
+        objs.append(make_object((float(rng.uniform(-8, 8)), float(rng.uniform(-8, 8)), float(rng.uniform(2, 8))), dim, api.PT_GEOM_CONE, rot=rot,
+                                color=(0.8, 0.6, 0.4), refl=1.0 if k % 2 else 0.0))
+    st = default_settings(320, 180, 16, 8, seed=99, grid_hint=8, brute_force_below=10)
+    img = gpu.render(world, objs, st)
+    sc = OracleScene(world, objs, st)
+    ref = sc.render(policy=3, threads=8)
+    paths = sc.path_count()
+    sc.close()
+    assert gpu.stats().paths == paths
+    fin = np.isfinite(ref).all(axis=2)
+    assert (np.isfinite(img).all(axis=2) == fin).all()
+    assert (bits(img[fin]) == bits(ref[fin])).all()
+
+
 def _crops_by_cost(cost, width, height, cw=32, ch=8):
     """Where a full-size frame is compared with the oracle: 32x8 crops (four tiles side by side) at the dearest tile, the
     cheapest tile that still casts more than its sixteen primary rays, three more of the dearest tiles of distinct tile
