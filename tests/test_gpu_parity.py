@@ -240,6 +240,24 @@ def test_per_sample_radiance_via_progressive_frames(gpu):
     sc.close()
 
 
+def test_progressive_frames_at_full_size(gpu):
+    """The interactive path at the headline size: six one-sample frames of the demo scene at 1920x1080, written straight to the
+    image by the trace kernel; every pixel of every frame is the oracle's accumulated frame, bit for bit."""
+    world, objs = scenes.default_scene()
+    st = default_settings(1920, 1080, 64, 8, seed=12345, frame_index=0)
+    gpu.prepare(world, objs, st)
+    sc = OracleScene(world, objs, st)
+    acc_ref = np.zeros((1080, 1920, 3), np.float32)
+    for f in range(6):
+        gpu.set_frame(f)
+        gpu.trace()
+        shown = gpu.download()
+        sc.lib.pto_progressive_frame(sc.h, f, P(acc_ref))
+        want = np.minimum(acc_ref / np.float32(f + 1), np.float32(1.0))
+        assert (bits(shown) == bits(want)).all(), (f, int((bits(shown) != bits(want)).any(axis=2).sum()))
+    sc.close()
+
+
 def test_progressive_converges_to_full_render(gpu):
     world, objs = scenes.default_scene()
     st_full = settings_for("default", 96, 54, 16, 8)
