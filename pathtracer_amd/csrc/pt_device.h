@@ -982,7 +982,10 @@ PT_DEV void get6(const v2f (&slot)[3], V3& a, V3& b) {
 // so skipping the entity does not change any result.  No divide, no square root.
 // This test decides nothing but which entities get the exact test, and its margins are a hundred times the rounding of
 // its arithmetic: it is the one place that uses fused multiply-adds (a third fewer instructions).
-PT_DEV bool sphere_rejects(V3 rp, V3 rd, v4f p0) {
+// line_only: the sphere may lie behind the origin.  For a cone in the cone-exact variants: the reference's cone intersector,
+// given a ray whose line grazes the apex of a cone behind it, can find one of two nearly equal roots above the apex and the other
+// below, replaces the first by the crossing of the base plane - which lies ahead - and reports that (code/raycast.cpp:352-388).
+PT_DEV bool sphere_rejects(V3 rp, V3 rd, v4f p0, bool line_only = false) {
 	V3 l = rp - v3(p0.x, p0.y, p0.z);
 	float dd = fdot(rd, rd), dl = fdot(rd, l), ll = fdot(l, l);
 	float r = __builtin_fmaf(p0.w, 1.002f, 1e-3f);
@@ -990,7 +993,7 @@ PT_DEV bool sphere_rejects(V3 rp, V3 rd, v4f p0) {
 	float dl2 = dl * dl;
 	float slack = 1e-5f * __builtin_fmaf(dd, ll, dl2);
 	float disc = __builtin_fmaf(-dd, ll - r2, dl2);
-	bool may_hit = (disc + slack >= 0) && (dl <= 0 || ll <= __builtin_fmaf(r2, 1.0001f, slack));
+	bool may_hit = (disc + slack >= 0) && (line_only || dl <= 0 || ll <= __builtin_fmaf(r2, 1.0001f, slack));
 	return !may_hit;
 }
 
@@ -1408,7 +1411,7 @@ PT_MARK("trip_loaded");
 						v4f ball = e[u];                 // the id's bits move the centre by less than the radius was enlarged by
 						ball.w = __uint_as_float(tag & 0xffff0000u);
 #ifndef PT_COOP_NO_FILTER
-						const bool keep = !sphere_rejects(op, od, ball);
+						const bool keep = !sphere_rejects(op, od, ball, CONES && (tag & 7u) == (uint32_t)KIND_CONE);
 						// CONES: a cone the ray stays clear of is looked at once more, below
 						if(CONES && !keep && (tag & 7u) == (uint32_t)KIND_CONE) {
 							cone_need[u] = true;
