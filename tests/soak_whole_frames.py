@@ -20,7 +20,7 @@ gpu = api.Renderer(0)
 bad = 0
 total_pixels = total_differ = 0
 for seed in range(first, first + count):
-    kind = seed % 5
+    kind = seed % 6
     if kind == 0:
         world, objs = scenes.mixed_scene(seed=seed, n=20 + (seed * 7) % 101, rough_share=0.0, spread=8.0 + seed % 13)
         st = api.default_settings(960, 540, 32, 8 + seed % 9, seed=1000 + seed, grid_hint=6 + seed % 7, brute_force_below=10)
@@ -30,6 +30,10 @@ for seed in range(first, first + count):
     elif kind == 2:
         world, objs = scenes.mixed_scene(seed=seed, n=20 + (seed * 7) % 101, spread=8.0 + seed % 13)
         st = api.default_settings(960, 540, 16, 8 + seed % 9, seed=1000 + seed, grid_hint=6 + seed % 7, brute_force_below=10)
+    elif kind == 5:
+        # crowded: a hundred entities in a few cells, so that lists are long, descriptors and pool run out and segments end early
+        world, objs = scenes.mixed_scene(seed=seed, n=80 + seed % 60, rough_share=0.0, spread=2.5 + seed % 3)
+        st = api.default_settings(960, 540, 32, 8 + seed % 9, seed=1000 + seed, grid_hint=2 + seed % 3, brute_force_below=10)
     elif kind == 4:
         world, objs = scenes.mixed_scene(seed=seed, n=2 + seed % 7, rough_share=0.0, spread=6.0 + seed % 5)     # below the threshold: the brute-force cast
         st = api.default_settings(960, 540, 32, 8 + seed % 9, seed=1000 + seed, grid_hint=6 + seed % 7, brute_force_below=10)
