@@ -390,6 +390,19 @@ int pt_host_grid(const float* records, int n, int hint, int32_t* grid_ints /* 9 
 int pt_host_list_entry(const float centre[3], float radius, uint32_t tag, uint32_t id, uint32_t entry[4], uint32_t* id_back);
 int pt_host_cell_order(const int32_t cell_count[3], const int32_t cell_size[3], int32_t stride[3]);
 
+/* What the cooperative grid cast's candidate filter knows of an entity, from its record (pt_host_flatten), exposed for tests;
+ * neither has a counterpart in the reference, which tests every listed entity exactly (code/raycast.cpp:957-983).
+ * pt_host_filter_sphere: a sphere that encloses the entity (centre xyz, radius; about the entity's position except for a cone,
+ * whose smallest enclosing sphere sits towards its base; an infinite radius for a plane).
+ * pt_host_cone_slopes: for a cone record, the eight numbers of the direction test that keeps a cone the ray stays clear of when
+ * the ray is parallel to one of the cone's generators (there the reference's intersector, code/raycast.cpp:352-388, divides by a
+ * rounded zero and reports a hit on the base plane): out[0..2] the cone's local x axis in the world, out[3] = (A - B) / C,
+ * out[4..6] its axis, out[7] = B / C with A = 4/dx^2, B = 4/dy^2, C = 1/dz^2; for a direction d,
+ * a = out[3] (d.x')^2 + out[7] (|d|^2 - (d.z')^2) - (d.z')^2 is zero exactly for the generators' directions.  Eight NaNs (every
+ * ray keeps the cone) for a record the formula does not fit. */
+int pt_host_filter_sphere(const float* record, float centre_radius[4]);
+int pt_host_cone_slopes(const float* record, float out[8]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -203,6 +203,8 @@ def load_core():
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.pt_host_list_entry.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.pt_host_cell_order.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.pt_host_filter_sphere.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.pt_host_cone_slopes.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.pt_sync.argtypes = [C.c_void_p]
     lib.pt_debug_grid.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32),
                                   C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]

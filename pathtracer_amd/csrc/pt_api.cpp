@@ -1966,6 +1966,21 @@ int pt_host_list_entry(const float centre[3], float radius, uint32_t tag, uint32
 	return PT_OK;
 }
 
+int pt_host_filter_sphere(const float* record, float centre_radius[4]) {
+	if(!record || !centre_radius) return PT_ERR_ARG;
+	centre_radius[3] = pt::filter_sphere(record, centre_radius);
+	return PT_OK;
+}
+
+int pt_host_cone_slopes(const float* record, float out[8]) {
+	if(!record || !out) return PT_ERR_ARG;
+	int32_t type;
+	memcpy(&type, record + PT_F_TYPE, 4);
+	if(type != PT_GEOM_CONE) return PT_ERR_ARG;
+	pt::cone_slopes(record, out);
+	return PT_OK;
+}
+
 int pt_host_cell_order(const int32_t cell_count[3], const int32_t cell_size[3], int32_t stride[3]) {
 	if(!cell_count || !cell_size || !stride) return PT_ERR_ARG;
 	ptl::GridDev g{};

@@ -245,3 +245,113 @@ def test_cell_order_puts_the_thinnest_cells_first(core_lib):
     assert order((68, 68, 104), (6, 6, 1)) == [104, 104 * 68, 1]
     assert order((4, 5, 6), (2, 1, 3)) == [5, 1, 20]
     assert order((4, 5, 6), (2, 2, 1)) == [6, 24, 1]
+
+
+def _quat_rotate(q, v):
+    """rot * v (Quat * Vec3, code/rt_math.cpp:2902-2907), in double precision."""
+    w, u = float(q[0]), np.array([q[1], q[2], q[3]], np.float64)
+    t = 2 * np.cross(u, v)
+    return v + w * t + np.cross(u, t)
+
+
+def _surface_points(o, rng, count):
+    """Points of an entity's surface in the world (double precision): its extreme points and random ones."""
+    half = np.array(o.dim[:], np.float64) / 2
+    pos = np.array(o.pos[:], np.float64)
+    if o.type == api.PT_GEOM_BOX:
+        local = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], np.float64) * half
+        local = np.vstack([local, rng.uniform(-1, 1, (count, 3)) * half])
+    elif o.type == api.PT_GEOM_SPHERE:
+        d = rng.normal(size=(count, 3))
+        local = d / np.linalg.norm(d, axis=1, keepdims=True) * half
+        local = np.vstack([local, np.diag(half), -np.diag(half)])
+    else:
+        ang = rng.uniform(0, 2 * np.pi, count)
+        ring = np.stack([np.cos(ang) * half[0], np.sin(ang) * half[1]], axis=1)
+        if o.type == api.PT_GEOM_CYLINDER:
+            z = np.where(rng.integers(0, 2, count) == 0, -half[2], half[2])
+            local = np.column_stack([ring, z])
+        else:       # cone: apex at +dz/2, base of semi-axes dx/2, dy/2 at -dz/2 (code/raycast.cpp:352-388 in unit space)
+            t = rng.uniform(0, 1, count)[:, None]
+            local = np.vstack([np.column_stack([ring * t, half[2] - 2 * half[2] * t[:, 0]]),
+                               np.column_stack([ring, np.full(count, -half[2])]), [[0, 0, half[2]]]])
+    return pos + np.array([_quat_rotate(o.rot, p) for p in local])
+
+
+def test_filter_sphere_encloses_the_entity(core_lib):
+    """The sphere the cooperative cast's filter knows of an entity holds every point of the entity's surface - for a cone it
+    is the smallest such sphere, through the apex and the base's rim, about a point below the entity's position."""
+    rng = np.random.default_rng(17)
+    world, objs = scenes.mixed_scene(seed=31, n=60)
+    _, dense = scenes.dense_scene(n=400, seed=5, half_extent=40.0, height=20.0)
+    objs = objs + dense
+    rec = np.zeros((len(objs), 36), np.float32)
+    assert core_lib.pt_host_flatten(object_array(objs), len(objs), fptr(rec)) == 0
+    tighter = 0
+    for i, o in enumerate(objs):
+        out = np.zeros(4, np.float32)
+        assert core_lib.pt_host_filter_sphere(fptr(rec[i]), fptr(out)) == 0
+        centre, radius = out[:3].astype(np.float64), float(out[3])
+        pts = _surface_points(o, rng, 64)
+        far = np.sqrt(((pts - centre) ** 2).sum(axis=1)).max()
+        assert far <= radius * (1 + 1e-6) + 1e-5, (i, o.type, far, radius)
+        assert radius <= far * 1.05 + 1e-3, (i, o.type, far, radius)          # and not much more (the sampled rim points miss the far end by a little)
+        if o.type == api.PT_GEOM_CONE:
+            half = np.array(o.dim[:], np.float64) / 2
+            tighter += radius < np.sqrt(max(half[0], half[1]) ** 2 + half[2] ** 2) * 0.999
+    assert tighter > 20
+    plane = api.make_object((0, 0, 0), (1, 1, 1), api.PT_GEOM_PLANE)
+    prec = np.zeros((1, 36), np.float32)
+    assert core_lib.pt_host_flatten(object_array([plane]), 1, fptr(prec)) == 0
+    out = np.zeros(4, np.float32)
+    assert core_lib.pt_host_filter_sphere(fptr(prec[0]), fptr(out)) == 0 and np.isinf(out[3])
+    assert core_lib.pt_host_filter_sphere(None, fptr(out)) != 0
+
+
+def test_cone_slopes_vanish_on_the_generators(core_lib):
+    """The direction test of the cone-exact trace variants: the form built from pt_host_cone_slopes is the reference's
+    a = dx^2 + dy^2 - dz^2 of the normalised unit-space direction (code/raycast.cpp:352-388) for any direction, zero for the
+    directions of the cone's generators; cones of extreme proportions get no data."""
+    rng = np.random.default_rng(23)
+    for k in range(200):
+        q = rng.normal(size=4)
+        q = q / np.linalg.norm(q) if k % 4 else np.array([1.0, 0, 0, 0])
+        dim = rng.uniform(0.4, 5.0, 3)
+        if k % 5 == 0:
+            dim[1] = dim[0]
+        o = api.make_object(tuple(rng.uniform(-20, 20, 3)), tuple(dim), api.PT_GEOM_CONE, rot=tuple(float(v) for v in q))
+        rec = np.zeros((1, 36), np.float32)
+        assert core_lib.pt_host_flatten(object_array([o]), 1, fptr(rec)) == 0
+        s = np.zeros(8, np.float32)
+        assert core_lib.pt_host_cone_slopes(fptr(rec[0]), fptr(s)) == 0
+        s = s.astype(np.float64)
+        qf = np.array(o.rot[:], np.float64)
+        conj = np.array([qf[0], -qf[1], -qf[2], -qf[3]])
+        df = np.array(o.dim[:], np.float64)
+
+        def form(d):
+            px, pz = np.dot(d, s[0:3]) ** 2, np.dot(d, s[4:7]) ** 2
+            a = s[3] * px + s[7] * (np.dot(d, d) - pz) - pz
+            return a / (a + 2 * pz)
+
+        def reference(d):
+            u = _quat_rotate(conj, d) * np.array([2 / df[0], 2 / df[1], 1 / df[2]])
+            u = u / np.linalg.norm(u)
+            return u[0] ** 2 + u[1] ** 2 - u[2] ** 2
+
+        for _ in range(8):
+            d = rng.normal(size=3)
+            d = d / np.linalg.norm(d)
+            assert abs(form(d) - reference(d)) < 2e-5, (k, form(d), reference(d))
+        ang = rng.uniform(0, 2 * np.pi)
+        gen = _quat_rotate(qf, np.array([np.cos(ang) * df[0] / 2, np.sin(ang) * df[1] / 2, -df[2]]))      # apex to a point of the base's rim
+        gen = gen / np.linalg.norm(gen)
+        assert abs(form(gen)) < 2e-5 and abs(form(-gen)) < 2e-5
+    needle = api.make_object((0, 0, 0), (0.05, 0.05, 6.0), api.PT_GEOM_CONE)
+    rec = np.zeros((1, 36), np.float32)
+    assert core_lib.pt_host_flatten(object_array([needle]), 1, fptr(rec)) == 0
+    s = np.zeros(8, np.float32)
+    assert core_lib.pt_host_cone_slopes(fptr(rec[0]), fptr(s)) == 0 and np.isnan(s).all()
+    ball = api.make_object((0, 0, 0), (1, 1, 1), api.PT_GEOM_SPHERE)
+    assert core_lib.pt_host_flatten(object_array([ball]), 1, fptr(rec)) == 0
+    assert core_lib.pt_host_cone_slopes(fptr(rec[0]), fptr(s)) != 0
