@@ -40,6 +40,16 @@ for seed in range(first, first + count):
     else:
         world, objs = scenes.planes_grid_scene(seed=seed, n=20 + (seed * 5) % 90)        # three planes among every kind and material
         st = api.default_settings(960, 540, 16, 8 + seed % 5, seed=1000 + seed, grid_hint=6 + seed % 7, brute_force_below=10)
+    if os.environ.get("PT_SOAK_VARY"):
+        # the settings varied as well: ragged image sizes, sample counts that are no power of two, explicit sample ranges,
+        # a wider blue-noise tile, depth of field
+        st.width, st.height = 960 - (seed * 13) % 40, 540 - (seed * 7) % 30
+        st.spp_wanted = (8, 12, 16, 27, 32, 48)[seed % 6]
+        st.sample_ranges = (0, 1, 2, 4, 8)[(seed // 6) % 5]
+        st.sample_grid_width = (3, 3, 4, 2)[(seed // 5) % 4]
+        if seed % 3 == 1:
+            world.aperture = 0.3 + (seed % 7) * 0.1
+            world.focal_distance = 20.0 + seed % 15
     t0 = time.time()
     img = gpu.render(world, objs, st)
     sc = OracleScene(world, objs, st)
